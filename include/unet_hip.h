@@ -1,0 +1,250 @@
+/*
+ * unet_hip.h -- C ABI of libunet_hip.so, the MI355X (gfx950) implementation of
+ * the U-Net layer operators.
+ *
+ * This header is the drop-in boundary: plain pointers and sizes, no C++ or
+ * torch types.  Each fp32 entry point replaces one host function template of
+ * the reference's operator API (src/cuda_library/cuda_lib.h, cited per
+ * function) and keeps that function's argument list, followed by one extra
+ * argument: the HIP stream to enqueue on (NULL = the null stream).
+ *
+ * Conventions
+ *   - every function returns UNET_OK (0) or an error code; the message of the
+ *     last error on the calling thread is unet_last_error();
+ *   - all pointers are device pointers unless the name says host;
+ *   - calls only ENQUEUE work on `stream` (no device synchronisation) unless
+ *     documented otherwise, so the host may run ahead of the GPU;
+ *   - tensors are NCHW contiguous fp32 (index = ((n*C + c)*H + h)*W + w,
+ *     cuda_lib.h:17-20); conv / transposed-conv weights are
+ *     [C_in][C_out][kh][kw] followed by C_out biases in the same buffer; BN
+ *     parameters are interleaved [gamma0,beta0,gamma1,beta1,...]; BN batch
+ *     statistics are interleaved raw sums [sum x, sum x^2]; running statistics
+ *     interleaved [mean,var]; Adam state interleaved [m,v] per parameter;
+ *   - element counts are 64-bit, so tensors of 2^31 elements and more work
+ *     (the reference's int counts do not).
+ */
+#ifndef UNET_HIP_H
+#define UNET_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UNET_OK 0
+#define UNET_ERR_INVALID 1     /* bad argument (shape, null pointer, ...) */
+#define UNET_ERR_HIP 2         /* a HIP runtime call or kernel launch failed */
+#define UNET_ERR_UNSUPPORTED 3 /* valid request this build has no kernel for */
+
+typedef void *unet_stream_t; /* hipStream_t */
+typedef void *unet_event_t;  /* hipEvent_t */
+
+/* ---- runtime ----------------------------------------------------------- */
+
+const char *unet_last_error(void);
+int unet_version(void);
+
+int unet_device_count(int *count);
+int unet_set_device(int device);
+int unet_get_device(int *device);
+/* Replaces cudaCheckErr (cuda_ops.cu:566-578): hipGetLastError +
+ * hipDeviceSynchronize, but returns the error instead of printing it. */
+int unet_device_synchronize(void);
+/* Replaces cudaGPUReset (cuda_ops.cu:554-564).  Synchronises the device and
+ * drops the library's cached workspace; it does not call hipDeviceReset, so
+ * other users of the device in the same process (e.g. torch) are unaffected. */
+int unet_device_reset(void);
+
+int unet_stream_create(unet_stream_t *stream);
+int unet_stream_destroy(unet_stream_t stream);
+int unet_stream_synchronize(unet_stream_t stream);
+int unet_event_create(unet_event_t *event);
+int unet_event_destroy(unet_event_t event);
+int unet_event_record(unet_event_t event, unet_stream_t stream);
+int unet_event_synchronize(unet_event_t event);
+int unet_stream_wait_event(unet_stream_t stream, unet_event_t event);
+int unet_event_elapsed_ms(float *ms, unet_event_t start, unet_event_t stop);
+
+/* ---- memory ------------------------------------------------------------ */
+
+/* Replaces cudaGetPointer<T>(n, ZERO) (cuda_ops.cu:32-57): allocate `bytes`
+ * of device memory and zero it. */
+int unet_malloc(void **ptr, size_t bytes);
+/* Replaces cudaLibFree (cuda_ops.cu:508). */
+int unet_free(void *ptr);
+int unet_host_malloc(void **ptr, size_t bytes); /* pinned host memory */
+int unet_host_free(void *ptr);
+int unet_memset(void *ptr, int value, size_t bytes, unet_stream_t stream);
+/* Replace cudaLibCopyToDevice / cudaLibCopyToHost / cudaLibCopyDeviceToDevice
+ * (cuda_ops.cu:580-597, 677-682).  Asynchronous with respect to the host when
+ * the host buffer is pinned; unet_memcpy_d2h is followed by a stream sync
+ * when `blocking` is non-zero. */
+int unet_memcpy_h2d(void *dst, const void *src_host, size_t bytes, unet_stream_t stream);
+int unet_memcpy_d2h(void *dst_host, const void *src, size_t bytes, int blocking, unet_stream_t stream);
+int unet_memcpy_d2d(void *dst, const void *src, size_t bytes, unet_stream_t stream);
+
+/* Replaces cudaGetPointer<T>(n, HE, N, num_weights) (cuda_ops.cu:12-22,43-49):
+ * weights[i] = normal(0,1) * sqrt(2/fan) for i < num_weights, from a
+ * counter-based generator keyed by (seed, i).  The reference draws from
+ * curand with seed 0, so values differ; the distribution is the same. */
+int unet_init_he_f32(float *weights, int64_t num_weights, int64_t fan, uint64_t seed, unet_stream_t stream);
+/* Replaces cudaGetPointer<T>(n, BN) (cuda_ops.cu:24-30,51-52):
+ * w[i] = (i % 2 == 0), i.e. gamma = 1, beta = 0 interleaved. */
+int unet_init_bn_f32(float *weights, int64_t num_weights, unet_stream_t stream);
+/* Replaces cudaHasNans (cuda_ops.cu:649-675) with an on-device scan:
+ * *has_nan_host = 1 when any element is NaN.  Synchronises `stream`. */
+int unet_has_nans_f32(const float *ptr, int64_t num_floats, int *has_nan_host, unet_stream_t stream);
+
+/* ---- convolution (cuda_lib.h:44-58, 162-177) ---------------------------- */
+
+/* Replaces cudaConvolve.  Y[n,co,h,w] = b[co] + sum W[ci,co,kh,kw] *
+ * X[n,ci,h*s-p+kh,w*s-p+kw], zero padding, square odd kernel. */
+int unet_convolve_f32(const float *weights, const float *inputs, float *activations,
+                      int64_t activation_array_length, int batch_size, int kernel_size,
+                      int channels_in, int channels_out, int H_out, int W_out, int H_in,
+                      int W_in, int padding, int stride, unet_stream_t stream);
+/* Replaces cudaConvolveBackward.  grad_weights (weights then biases) is
+ * overwritten.  grad_inputs may be NULL to skip the data gradient (first
+ * layer). */
+int unet_convolve_backward_f32(const float *grad_activations, const float *inputs,
+                               const float *weights, float *grad_inputs, float *grad_weights,
+                               int batch_size, int kernel_size, int channels_in,
+                               int channels_out, int H_out, int W_out, int H_in, int W_in,
+                               int padding, int stride, unet_stream_t stream);
+
+/* ---- batch norm (cuda_lib.h:100-118, 179-189) --------------------------- */
+
+/* Replaces cudaBatchNormTrain: raw sums -> BN_batch_stats; y = gamma*(x-mean)/
+ * (sqrt(var)+1e-8)+beta with the biased batch variance; running [mean,var] =
+ * 0.9*old + 0.1*batch.  BN_running_stats may be NULL. */
+int unet_batch_norm_train_f32(const float *inputs, float *activations, const float *weights,
+                              float *BN_batch_stats, float *BN_running_stats, int num_channels,
+                              int H, int W, int batch_size, unet_stream_t stream);
+/* Replaces cudaBatchNormInference: y = gamma*(x-mean)/sqrt(var+1e-8)+beta with
+ * the running statistics.  Extra argument batch_size (the reference handles
+ * one image only). */
+int unet_batch_norm_inference_f32(const float *inputs, float *activations, const float *weights,
+                                  const float *BN_stats, int H, int W, int num_channels,
+                                  int batch_size, unet_stream_t stream);
+/* Replaces cudaBatchNormBackward: grad_weights[2c] = sum dy*xhat,
+ * grad_weights[2c+1] = sum dy; dx = gamma/sqrt(var+eps)*(dy - (dbeta +
+ * xhat*dgamma)/M). */
+int unet_batch_norm_backward_f32(const float *grad_activations, const float *inputs,
+                                 const float *BN_batch_stats, const float *weights,
+                                 float *grad_inputs, float *grad_weights, int num_channels,
+                                 int H, int W, int batch_size, unet_stream_t stream);
+
+/* ---- activations (cuda_lib.h:90-98, 151-161) ---------------------------- */
+
+int unet_relu_f32(const float *inputs, float *activations, int64_t num_activations, unet_stream_t stream);
+/* inputs = the PRE-activation values. */
+int unet_relu_backward_f32(const float *grad_activations, const float *inputs, float *grad_inputs,
+                           int64_t num_activations, unet_stream_t stream);
+int unet_sigmoid_f32(const float *inputs, float *activations, int64_t num_activations, unet_stream_t stream);
+/* activations = the sigmoid OUTPUT. */
+int unet_sigmoid_backward_f32(const float *grad_activations, const float *activations,
+                              float *grad_inputs, int64_t num_activations, unet_stream_t stream);
+
+/* ---- max pool (cuda_lib.h:69-77, 202-211) -------------------------------- */
+
+/* Replaces cudaMaxPool: k x k window at (ho*s, wo*s), no padding,
+ * H_out = H/s, W_out = W/s. */
+int unet_max_pool_f32(const float *inputs, float *activations, int batch_size, int stride,
+                      int kernel_size, int in_channels, int in_height, int in_width,
+                      unet_stream_t stream);
+/* As unet_max_pool_f32, and also writes (either may be NULL)
+ *   indices[n,c,ho,wo]: int32 flat index hi*W+wi of the first maximum in
+ *     row-major window order (PyTorch's return_indices convention);
+ *   tiemask[n,c,ho,wo]: bit (i*k+j) set when window element (i,j) equals the
+ *     maximum (first 8 window positions). */
+int unet_max_pool_indices_f32(const float *inputs, float *activations, int32_t *indices,
+                              uint8_t *tiemask, int batch_size, int stride, int kernel_size,
+                              int in_channels, int in_height, int in_width, unet_stream_t stream);
+/* Replaces cudaMaxPoolBackward: dX = (X == Y[h/s,w/s]) ? dY[h/s,w/s] : 0, so
+ * every tied maximum receives the gradient (max_pool.cu:172). */
+int unet_max_pool_backward_f32(const float *grad_activations, const float *inputs,
+                               const float *activations, float *grad_inputs, int batch_size,
+                               int stride, int in_channels, int in_height, int in_width,
+                               unet_stream_t stream);
+/* Index-based backward (PyTorch semantics: only the saved argmax receives
+ * the gradient).  No counterpart in the reference.  kernel_size <= stride. */
+int unet_max_pool_backward_indices_f32(const float *grad_activations, const int32_t *indices,
+                                       float *grad_inputs, int batch_size, int in_channels,
+                                       int in_height, int in_width, int out_height,
+                                       int out_width, unet_stream_t stream);
+
+/* ---- upsample = transposed conv, kernel = stride = scale ---------------- */
+/* (cuda_lib.h:79-88, 213-224) */
+
+int unet_upsample_f32(const float *inputs, const float *weights, float *activations, int scale,
+                      int num_in_channels, int num_out_channels, int H_in, int W_in,
+                      int batch_size, unet_stream_t stream);
+/* grad_weights (weights then biases) is overwritten; grad_inputs may be NULL. */
+int unet_upsample_backward_f32(const float *grad_activations, const float *inputs,
+                               const float *weights, float *grad_inputs, float *grad_weights,
+                               int scale, int channels_in, int channels_out, int H_in, int W_in,
+                               int batch_size, unet_stream_t stream);
+
+/* ---- concat (cuda_lib.h:60-67, 191-198) ---------------------------------- */
+
+/* Replaces cudaConcat: out[n,0:C1] = A[n], out[n,C1:C1+C2] = B[n]. */
+int unet_concat_f32(const float *activations_1, const float *activations_2, float *activations,
+                    int batch_size, int64_t HxW, int C1, int C2, unet_stream_t stream);
+/* Replaces cudaConcatBackward.  dLdX receives the two parents' gradients back
+ * to back: dLdX[0 : N*C1*HW] = dA as [N,C1,H,W], then dB as [N,C2,H,W] -- the
+ * layout the reference's Layer::backward slices (layer.h:150-165).  (The
+ * reference copies dLdY unchanged, which equals this only for batch 1.) */
+int unet_concat_backward_f32(const float *dLdY, float *dLdX, int H, int W, int C1, int C2,
+                             int batch_size, unet_stream_t stream);
+
+/* ---- losses (cuda_lib.h:32-36, 134-149) ---------------------------------- */
+
+/* The kernel half of cudaDiceScore: loss_values[3n..3n+2] = [sum m*p, sum m,
+ * sum p] per sample (deterministic; the reference uses float atomics). */
+int unet_dice_sums_f32(const float *mask, const float *prediction, int H, int W, int batch_size,
+                       float *loss_values, unet_stream_t stream);
+/* Replaces cudaDiceScore: unet_dice_sums_f32, then copies the sums to the
+ * host (synchronises `stream`) and returns mean_n 2*I/(sum m + sum p + 1e-5)
+ * in *dice_host. */
+int unet_dice_score_f32(const float *mask, const float *prediction, int H, int W, int batch_size,
+                        float *loss_values, float *dice_host, unet_stream_t stream);
+/* Replaces cudaDiceLossBackward: dLdY = scale * 2*(m*D - I)/D^2 with
+ * D = sum m + sum p + 1e-5 read from loss_values.  scale = 1 reproduces the
+ * reference; scale = -1/N gives the gradient of the loss 1 - mean dice. */
+int unet_dice_loss_backward_f32(const float *mask, const float *prediction,
+                                const float *loss_values, float *dLdY, int H, int W,
+                                int batch_size, float scale, unet_stream_t stream);
+/* Replaces cudaDifferenceLossBackward: dLdY = (y - mask)/total_size. */
+int unet_difference_loss_backward_f32(const float *mask, const float *y, float *dLdY,
+                                      int64_t total_size, unet_stream_t stream);
+/* Softmax cross-entropy over the channel axis, mean over N*H*W pixels
+ * (torch.nn.functional.cross_entropy semantics; the reference only names
+ * SOFTMAX in an enum, layer.h:31).  logits [N,C,H,W], target int32 [N,H,W];
+ * loss_out = device float (mean loss); dlogits may be NULL. */
+int unet_softmax_xent_f32(const float *logits, const int32_t *target, float *dlogits,
+                          float *loss_out, int batch_size, int num_classes, int H, int W,
+                          unet_stream_t stream);
+
+/* ---- optimiser and small ops (cuda_lib.h:29-30, 245-259) ----------------- */
+
+/* Replaces cudaUpdateWeights (6 arguments): Adam, beta1 .9, beta2 .999,
+ * eps 1e-8, decoupled weight decay 1e-4; t = 1-based step. */
+int unet_update_weights_adam_f32(float *weights, const float *dLdW, float *adam_parameters,
+                                 float learning_rate, int64_t num_weights, int t,
+                                 unet_stream_t stream);
+/* Replaces cudaUpdateWeights (4 arguments): w -= lr*g. */
+int unet_update_weights_sgd_f32(float *weights, const float *dLdW, float learning_rate,
+                                int64_t num_weights, unet_stream_t stream);
+/* Replaces cudaAddBtoA: a += b. */
+int unet_add_b_to_a_f32(float *a, const float *b, int64_t num_floats, unet_stream_t stream);
+/* Replaces cudaThreshold: x = x >= t ? 1 : 0. */
+int unet_threshold_f32(float *x, float threshold, int64_t num_elements, unet_stream_t stream);
+/* x *= alpha (gradient averaging across data-parallel ranks). */
+int unet_scale_f32(float *x, float alpha, int64_t num_elements, unet_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UNET_HIP_H */

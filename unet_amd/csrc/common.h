@@ -1,0 +1,86 @@
+// Shared helpers for the HIP sources of libunet_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/unet_hip.h"
+
+typedef int64_t i64;
+
+// Records `msg` as the calling thread's last error and returns `code`.
+int unet_set_error(int code, const char *fmt, ...);
+
+#define UNET_HIP_TRY(expr)                                                          \
+  do {                                                                              \
+    hipError_t e_ = (expr);                                                         \
+    if (e_ != hipSuccess)                                                           \
+      return unet_set_error(UNET_ERR_HIP, "%s failed: %s (%s:%d)", #expr,           \
+                            hipGetErrorString(e_), __FILE__, __LINE__);             \
+  } while (0)
+
+#define UNET_REQUIRE(cond, ...)                                  \
+  do {                                                           \
+    if (!(cond)) return unet_set_error(UNET_ERR_INVALID, __VA_ARGS__); \
+  } while (0)
+
+// After a kernel launch: report launch-configuration errors.
+#define UNET_LAUNCH_CHECK(name)                                                     \
+  do {                                                                              \
+    hipError_t e_ = hipGetLastError();                                              \
+    if (e_ != hipSuccess)                                                           \
+      return unet_set_error(UNET_ERR_HIP, "launch of %s failed: %s", name,          \
+                            hipGetErrorString(e_));                                 \
+  } while (0)
+
+// Grow-only per-device scratch used by reductions that need partial results.
+// Returned memory is valid until the next unet_workspace() call on the same
+// device that asks for more bytes; all users enqueue on one stream at a time.
+int unet_workspace(void **ptr, size_t bytes);
+void unet_workspace_release_all();
+
+static inline hipStream_t as_stream(unet_stream_t s) { return (hipStream_t)s; }
+
+static inline unsigned cdiv_u(i64 a, i64 b) { return (unsigned)((a + b - 1) / b); }
+
+// Grid for grid-stride elementwise kernels: enough blocks to fill 256 CUs
+// several times over, capped so very large tensors loop instead.
+static inline unsigned ew_grid(i64 work_items, int block = 256) {
+  i64 g = (work_items + block - 1) / block;
+  if (g < 1) g = 1;
+  if (g > 8192) g = 8192;
+  return (unsigned)g;
+}
+
+#ifdef __HIPCC__
+// 64-lane wavefront sum via xor shuffles; every lane ends with the total.
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// Block-wide sum of NV values per thread for blocks of up to 1024 threads.
+// `red` must hold NV * (blockDim.x/64) floats.  Result valid in thread 0
+// (all lanes of wave 0 hold it).
+template <int NV>
+__device__ __forceinline__ void block_sum(float (&v)[NV], float *red) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) v[i] = wave_sum(v[i]);
+  if (nw == 1) return;
+  __syncthreads();
+  if (lane == 0)
+#pragma unroll
+    for (int i = 0; i < NV; ++i) red[wid * NV + i] = v[i];
+  __syncthreads();
+  if (wid == 0) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      float s = 0.f;
+      for (int w = 0; w < nw; ++w) s += red[w * NV + i];
+      v[i] = s;
+    }
+  }
+}
+#endif

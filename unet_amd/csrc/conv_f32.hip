@@ -1,0 +1,529 @@
+// fp32 NCHW convolution and transposed convolution (part 2 of the fp32
+// operator set).  LDS-tiled direct kernels on the fp32 vector pipe: every
+// product is an fmaf in fp32, reductions over pixels are tree sums with a
+// fixed order (deterministic, no atomics).
+//
+// Weight layout everywhere: [C_in][C_out][k][k] followed by C_out biases
+// (src/cuda_library/2Dconvolution/convolution.cu:44-46,77-78).
+#include "common.h"
+
+namespace {
+
+constexpr int TILE = 16;  // a block covers a 16x16 pixel tile (256 threads)
+
+__device__ __forceinline__ void fma4x4(float (&acc)[16], float v, const float *w) {
+  const float4 *w4 = reinterpret_cast<const float4 *>(w);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float4 t = w4[q];
+    acc[4 * q + 0] = fmaf(v, t.x, acc[4 * q + 0]);
+    acc[4 * q + 1] = fmaf(v, t.y, acc[4 * q + 1]);
+    acc[4 * q + 2] = fmaf(v, t.z, acc[4 * q + 2]);
+    acc[4 * q + 3] = fmaf(v, t.w, acc[4 * q + 3]);
+  }
+}
+
+// ---------------------------------------------------------------- forward --
+// Block: one image, a 16x16 output tile, COB=16 output channels.  Loops over
+// input channels in chunks of CIB=8, staging the input halo patch
+// ((15*stride + k)^2 per channel) and the weight slice [ci][tap][co] in LDS.
+constexpr int F_COB = 16, F_CIB = 8;
+
+template <int K>  // compile-time kernel size, 0 = runtime
+__global__ __launch_bounds__(256) void conv_fwd_f32_kernel(
+    const float *__restrict__ Wt, const float *__restrict__ X, float *__restrict__ Y, int Ci, int Co,
+    int Ho, int Wo, int Hi, int Wi, int pad, int stride, int k_rt, int tilesW) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int k = K ? K : k_rt;
+  const int kk = k * k;
+  const int PH = (TILE - 1) * stride + k;
+  const int PWp = PH + 1;
+  float *patch = smem;                                                 // [CIB][PH][PWp]
+  float *wts = smem + ((F_CIB * PH * PWp + 3) & ~3);                   // [CIB][kk][COB]
+  const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+  const int th0 = (blockIdx.x / tilesW) * TILE, tw0 = (blockIdx.x % tilesW) * TILE;
+  const int co0 = blockIdx.y * F_COB;
+  const i64 n = blockIdx.z;
+  const int ih0 = th0 * stride - pad, iw0 = tw0 * stride - pad;
+  float acc[F_COB];
+#pragma unroll
+  for (int i = 0; i < F_COB; ++i) acc[i] = 0.f;
+
+  for (int ci0 = 0; ci0 < Ci; ci0 += F_CIB) {
+    __syncthreads();
+    for (int e = tid; e < F_CIB * PH * PH; e += 256) {
+      const int ci = e / (PH * PH), r = e - ci * PH * PH, ph = r / PH, pw = r - ph * PH;
+      const int ih = ih0 + ph, iw = iw0 + pw;
+      float v = 0.f;
+      if (ci0 + ci < Ci && ih >= 0 && ih < Hi && iw >= 0 && iw < Wi)
+        v = X[((n * Ci + ci0 + ci) * Hi + ih) * Wi + iw];
+      patch[(ci * PH + ph) * PWp + pw] = v;
+    }
+    for (int e = tid; e < F_CIB * kk * F_COB; e += 256) {
+      const int co = e % F_COB, r = e / F_COB, t = r % kk, ci = r / kk;
+      float v = 0.f;
+      if (ci0 + ci < Ci && co0 + co < Co) v = Wt[((i64)(ci0 + ci) * Co + co0 + co) * kk + t];
+      wts[e] = v;
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int ci = 0; ci < F_CIB; ++ci) {
+      const float *prow = patch + (ci * PH + ty * stride) * PWp + tx * stride;
+      const float *wrow = wts + ci * kk * F_COB;
+      for (int kh = 0; kh < k; ++kh)
+        for (int kw = 0; kw < k; ++kw) fma4x4(acc, prow[kh * PWp + kw], wrow + (kh * k + kw) * F_COB);
+    }
+  }
+  const int ho = th0 + ty, wo = tw0 + tx;
+  if (ho < Ho && wo < Wo) {
+    const float *bias = Wt + (i64)Ci * Co * kk;
+#pragma unroll
+    for (int co = 0; co < F_COB; ++co)
+      if (co0 + co < Co) Y[((n * Co + co0 + co) * Ho + ho) * Wo + wo] = acc[co] + bias[co0 + co];
+  }
+}
+
+// ---------------------------------------------------------- backward data --
+// dX[n,ci,hi,wi] = sum_co sum_kh,kw W[ci,co,kh,kw] * dY[n,co,(hi+p-kh)/s,(wi+p-kw)/s]
+// over taps where the division is exact and the result is in range
+// (convolution.cu:198-200).  Block: one image, 16x16 input tile, CIB=16 input
+// channels; loops over output channels in chunks of COC=8 staging the dY patch.
+constexpr int D_CIB = 16, D_COC = 8;
+
+__global__ __launch_bounds__(256) void conv_bwd_data_f32_kernel(
+    const float *__restrict__ Wt, const float *__restrict__ dY, float *__restrict__ dX, int Ci, int Co,
+    int Ho, int Wo, int Hi, int Wi, int pad, int stride, int k, int tilesW, int PH) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int kk = k * k;
+  const int PWp = PH + 1;
+  float *patch = smem;                                     // [COC][PH][PWp]
+  float *wts = smem + ((D_COC * PH * PWp + 3) & ~3);       // [COC][kk][CIB]
+  const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+  const int h0 = (blockIdx.x / tilesW) * TILE, w0 = (blockIdx.x % tilesW) * TILE;
+  const int ci0 = blockIdx.y * D_CIB;
+  const i64 n = blockIdx.z;
+  // lowest output row/col any tap of this tile can touch (floor division)
+  const int a = h0 + pad - (k - 1), b = w0 + pad - (k - 1);
+  const int ho_lo = (a >= 0) ? a / stride : -((-a + stride - 1) / stride);
+  const int wo_lo = (b >= 0) ? b / stride : -((-b + stride - 1) / stride);
+  const int hi = h0 + ty, wi = w0 + tx;
+  float acc[D_CIB];
+#pragma unroll
+  for (int i = 0; i < D_CIB; ++i) acc[i] = 0.f;
+
+  for (int co0 = 0; co0 < Co; co0 += D_COC) {
+    __syncthreads();
+    for (int e = tid; e < D_COC * PH * PH; e += 256) {
+      const int co = e / (PH * PH), r = e - co * PH * PH, ph = r / PH, pw = r - ph * PH;
+      const int ho = ho_lo + ph, wo = wo_lo + pw;
+      float v = 0.f;
+      if (co0 + co < Co && ho >= 0 && ho < Ho && wo >= 0 && wo < Wo)
+        v = dY[((n * Co + co0 + co) * Ho + ho) * Wo + wo];
+      patch[(co * PH + ph) * PWp + pw] = v;
+    }
+    for (int e = tid; e < D_COC * kk * D_CIB; e += 256) {
+      const int ci = e % D_CIB, r = e / D_CIB, t = r % kk, co = r / kk;
+      float v = 0.f;
+      if (ci0 + ci < Ci && co0 + co < Co) v = Wt[((i64)(ci0 + ci) * Co + co0 + co) * kk + t];
+      wts[e] = v;
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int co = 0; co < D_COC; ++co) {
+      for (int kh = 0; kh < k; ++kh) {
+        const int th = hi + pad - kh;
+        if (th % stride) continue;
+        const int ph = th / stride - ho_lo;
+        for (int kw = 0; kw < k; ++kw) {
+          const int tw = wi + pad - kw;
+          if (tw % stride) continue;
+          const int pw = tw / stride - wo_lo;
+          fma4x4(acc, patch[(co * PH + ph) * PWp + pw], wts + (co * kk + kh * k + kw) * D_CIB);
+        }
+      }
+    }
+  }
+  if (hi < Hi && wi < Wi) {
+#pragma unroll
+    for (int ci = 0; ci < D_CIB; ++ci)
+      if (ci0 + ci < Ci) dX[((n * Ci + ci0 + ci) * Hi + hi) * Wi + wi] = acc[ci];
+  }
+}
+
+// -------------------------------------------------------- backward weights --
+// dW[ci,co,kh,kw] = sum_{n,ho,wo} dY[n,co,ho,wo] * X[n,ci,ho*s-p+kh,wo*s-p+kw];
+// db[co] = sum dY.  Block (split, co-group, ci): each thread walks pixels of
+// the split's rows with COB*K*K private accumulators, then the block reduces
+// them (wave shuffles + LDS) into partial[split][...]; reduce_partials_kernel
+// sums the splits in a fixed order.
+template <int K, int COB>
+__global__ __launch_bounds__(256) void conv_bwd_weight_f32_kernel(
+    const float *__restrict__ dY, const float *__restrict__ X, float *__restrict__ partial, int N, int Ci,
+    int Co, int Ho, int Wo, int Hi, int Wi, int pad, int stride, int rows_per_split, i64 nW) {
+  constexpr int KK = K * K, NACC = COB * KK + COB;
+  __shared__ float red[4 * NACC];
+  const int split = blockIdx.x, co0 = blockIdx.y * COB, ci = blockIdx.z;
+  const int rows = N * Ho;
+  const int r0 = split * rows_per_split;
+  const int r1 = min(rows, r0 + rows_per_split);
+  float acc[NACC];
+#pragma unroll
+  for (int i = 0; i < NACC; ++i) acc[i] = 0.f;
+  const i64 npix = (i64)max(0, r1 - r0) * Wo;
+  for (i64 p = threadIdx.x; p < npix; p += 256) {
+    const int r = r0 + (int)(p / Wo), wo = (int)(p % Wo);
+    const i64 n = r / Ho;
+    const int ho = r % Ho;
+    float g[COB];
+#pragma unroll
+    for (int c = 0; c < COB; ++c) {
+      g[c] = (co0 + c < Co) ? dY[((n * Co + co0 + c) * Ho + ho) * Wo + wo] : 0.f;
+      acc[COB * KK + c] += g[c];
+    }
+    const float *xp = X + (n * Ci + ci) * (i64)Hi * Wi;
+#pragma unroll
+    for (int kh = 0; kh < K; ++kh) {
+      const int ih = ho * stride - pad + kh;
+#pragma unroll
+      for (int kw = 0; kw < K; ++kw) {
+        const int iw = wo * stride - pad + kw;
+        const float xv = (ih >= 0 && ih < Hi && iw >= 0 && iw < Wi) ? xp[(i64)ih * Wi + iw] : 0.f;
+#pragma unroll
+        for (int c = 0; c < COB; ++c) acc[c * KK + kh * K + kw] = fmaf(g[c], xv, acc[c * KK + kh * K + kw]);
+      }
+    }
+  }
+  // wave totals -> LDS, then thread i adds the four wave totals of value i
+#pragma unroll
+  for (int i = 0; i < NACC; ++i) acc[i] = wave_sum(acc[i]);
+  if ((threadIdx.x & 63) == 0)
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) red[(threadIdx.x >> 6) * NACC + i] = acc[i];
+  __syncthreads();
+  if (threadIdx.x < NACC) {
+    const int i = threadIdx.x;
+    const float v = (red[i] + red[NACC + i]) + (red[2 * NACC + i] + red[3 * NACC + i]);
+    if (i < COB * KK) {
+      const int c = i / KK, t = i % KK;
+      if (co0 + c < Co) partial[(i64)split * (nW + Co) + ((i64)ci * Co + co0 + c) * KK + t] = v;
+    } else if (ci == 0) {
+      const int c = i - COB * KK;
+      if (co0 + c < Co) partial[(i64)split * (nW + Co) + nW + co0 + c] = v;
+    }
+  }
+}
+
+// out[i] = sum_s partial[s*stride_s + i], i < n  (double accumulation)
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float *__restrict__ partial,
+                                                              float *__restrict__ out, i64 n, int splits) {
+  for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (i64)gridDim.x * blockDim.x) {
+    double s = 0;
+    for (int k = 0; k < splits; ++k) s += partial[(i64)k * n + i];
+    out[i] = (float)s;
+  }
+}
+
+// ------------------------------------------------------------- upsample ----
+// Transposed convolution with kernel = stride = s (upsample.cu:9-59):
+// Y[n,co,h,w] = b[co] + sum_ci W[ci,co,h%s,w%s] * X[n,ci,h/s,w/s].
+constexpr int U_COB = 8, U_CIC = 16;
+
+__global__ __launch_bounds__(256) void upsample_fwd_f32_kernel(
+    const float *__restrict__ X, const float *__restrict__ Wt, float *__restrict__ Y, int Ci, int Co,
+    int Hi, int Wi, int s) {
+  extern __shared__ __attribute__((aligned(16))) float wts[];  // [CIC][ss][COB]
+  const int ss = s * s, Ho = Hi * s, Wo = Wi * s;
+  const i64 pix = (i64)blockIdx.x * 256 + threadIdx.x;  // output pixel within the image
+  const int co0 = blockIdx.y * U_COB;
+  const i64 n = blockIdx.z;
+  const bool live = pix < (i64)Ho * Wo;
+  const int ho = live ? (int)(pix / Wo) : 0, wo = live ? (int)(pix % Wo) : 0;
+  const int pp = (ho % s) * s + (wo % s);
+  const float *xp = X + n * Ci * (i64)Hi * Wi + (i64)(ho / s) * Wi + (wo / s);
+  float acc[U_COB];
+#pragma unroll
+  for (int i = 0; i < U_COB; ++i) acc[i] = 0.f;
+  for (int ci0 = 0; ci0 < Ci; ci0 += U_CIC) {
+    __syncthreads();
+    for (int e = threadIdx.x; e < U_CIC * ss * U_COB; e += 256) {
+      const int co = e % U_COB, r = e / U_COB, t = r % ss, ci = r / ss;
+      float v = 0.f;
+      if (ci0 + ci < Ci && co0 + co < Co) v = Wt[((i64)(ci0 + ci) * Co + co0 + co) * ss + t];
+      wts[e] = v;
+    }
+    __syncthreads();
+    const int cmax = min(U_CIC, Ci - ci0);
+    for (int ci = 0; ci < cmax; ++ci) {
+      const float xv = live ? xp[(i64)(ci0 + ci) * Hi * Wi] : 0.f;
+      const float4 *w4 = reinterpret_cast<const float4 *>(wts + (ci * ss + pp) * U_COB);
+      const float4 a = w4[0], b = w4[1];
+      acc[0] = fmaf(xv, a.x, acc[0]); acc[1] = fmaf(xv, a.y, acc[1]);
+      acc[2] = fmaf(xv, a.z, acc[2]); acc[3] = fmaf(xv, a.w, acc[3]);
+      acc[4] = fmaf(xv, b.x, acc[4]); acc[5] = fmaf(xv, b.y, acc[5]);
+      acc[6] = fmaf(xv, b.z, acc[6]); acc[7] = fmaf(xv, b.w, acc[7]);
+    }
+  }
+  if (live) {
+    const float *bias = Wt + (i64)Ci * Co * ss;
+#pragma unroll
+    for (int co = 0; co < U_COB; ++co)
+      if (co0 + co < Co) Y[((n * Co + co0 + co) * Ho + ho) * Wo + wo] = acc[co] + bias[co0 + co];
+  }
+}
+
+// dX[n,ci,hi,wi] = sum_co sum_{i,j<s} W[ci,co,i,j] * dY[n,co,hi*s+i,wi*s+j]
+constexpr int UD_CIB = 8, UD_COC = 8;
+
+__global__ __launch_bounds__(256) void upsample_bwd_data_f32_kernel(
+    const float *__restrict__ dY, const float *__restrict__ Wt, float *__restrict__ dX, int Ci, int Co,
+    int Hi, int Wi, int s) {
+  extern __shared__ __attribute__((aligned(16))) float wts[];  // [COC][ss][CIB]
+  const int ss = s * s, Ho = Hi * s, Wo = Wi * s;
+  const i64 pix = (i64)blockIdx.x * 256 + threadIdx.x;  // input pixel within the image
+  const int ci0 = blockIdx.y * UD_CIB;
+  const i64 n = blockIdx.z;
+  const bool live = pix < (i64)Hi * Wi;
+  const int hi = live ? (int)(pix / Wi) : 0, wi = live ? (int)(pix % Wi) : 0;
+  const float *gp = dY + n * Co * (i64)Ho * Wo + (i64)(hi * s) * Wo + wi * s;
+  float acc[UD_CIB];
+#pragma unroll
+  for (int i = 0; i < UD_CIB; ++i) acc[i] = 0.f;
+  for (int co0 = 0; co0 < Co; co0 += UD_COC) {
+    __syncthreads();
+    for (int e = threadIdx.x; e < UD_COC * ss * UD_CIB; e += 256) {
+      const int ci = e % UD_CIB, r = e / UD_CIB, t = r % ss, co = r / ss;
+      float v = 0.f;
+      if (ci0 + ci < Ci && co0 + co < Co) v = Wt[((i64)(ci0 + ci) * Co + co0 + co) * ss + t];
+      wts[e] = v;
+    }
+    __syncthreads();
+    const int cmax = min(UD_COC, Co - co0);
+    if (live)
+      for (int co = 0; co < cmax; ++co)
+        for (int i = 0; i < s; ++i)
+          for (int j = 0; j < s; ++j) {
+            const float g = gp[(i64)(co0 + co) * Ho * Wo + (i64)i * Wo + j];
+            const float4 *w4 = reinterpret_cast<const float4 *>(wts + (co * ss + i * s + j) * UD_CIB);
+            const float4 a = w4[0], b = w4[1];
+            acc[0] = fmaf(g, a.x, acc[0]); acc[1] = fmaf(g, a.y, acc[1]);
+            acc[2] = fmaf(g, a.z, acc[2]); acc[3] = fmaf(g, a.w, acc[3]);
+            acc[4] = fmaf(g, b.x, acc[4]); acc[5] = fmaf(g, b.y, acc[5]);
+            acc[6] = fmaf(g, b.z, acc[6]); acc[7] = fmaf(g, b.w, acc[7]);
+          }
+  }
+  if (live)
+#pragma unroll
+    for (int ci = 0; ci < UD_CIB; ++ci)
+      if (ci0 + ci < Ci) dX[((n * Ci + ci0 + ci) * Hi + hi) * Wi + wi] = acc[ci];
+}
+
+// dW[ci,co,i,j] = sum_{n,hi,wi} dY[n,co,hi*s+i,wi*s+j] * X[n,ci,hi,wi]; db[co] = sum dY.
+template <int S, int COB>
+__global__ __launch_bounds__(256) void upsample_bwd_weight_f32_kernel(
+    const float *__restrict__ dY, const float *__restrict__ X, float *__restrict__ partial, int N, int Ci,
+    int Co, int Hi, int Wi, int rows_per_split, i64 nW) {
+  constexpr int SS = S * S, NACC = COB * SS + COB;
+  __shared__ float red[4 * NACC];
+  const int split = blockIdx.x, co0 = blockIdx.y * COB, ci = blockIdx.z;
+  const int Ho = Hi * S, Wo = Wi * S;
+  const int rows = N * Hi;
+  const int r0 = split * rows_per_split;
+  const int r1 = min(rows, r0 + rows_per_split);
+  float acc[NACC];
+#pragma unroll
+  for (int i = 0; i < NACC; ++i) acc[i] = 0.f;
+  const i64 npix = (i64)max(0, r1 - r0) * Wi;
+  for (i64 p = threadIdx.x; p < npix; p += 256) {
+    const int r = r0 + (int)(p / Wi), wi = (int)(p % Wi);
+    const i64 n = r / Hi;
+    const int hi = r % Hi;
+    const float xv = X[((n * Ci + ci) * Hi + hi) * Wi + wi];
+#pragma unroll
+    for (int c = 0; c < COB; ++c) {
+      if (co0 + c < Co) {
+        const float *gp = dY + ((n * Co + co0 + c) * Ho + (i64)hi * S) * Wo + (i64)wi * S;
+#pragma unroll
+        for (int i = 0; i < S; ++i)
+#pragma unroll
+          for (int j = 0; j < S; ++j) {
+            const float g = gp[(i64)i * Wo + j];
+            acc[c * SS + i * S + j] = fmaf(g, xv, acc[c * SS + i * S + j]);
+            acc[COB * SS + c] += g;
+          }
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NACC; ++i) acc[i] = wave_sum(acc[i]);
+  if ((threadIdx.x & 63) == 0)
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) red[(threadIdx.x >> 6) * NACC + i] = acc[i];
+  __syncthreads();
+  if (threadIdx.x < NACC) {
+    const int i = threadIdx.x;
+    const float v = (red[i] + red[NACC + i]) + (red[2 * NACC + i] + red[3 * NACC + i]);
+    if (i < COB * SS) {
+      const int c = i / SS, t = i % SS;
+      if (co0 + c < Co) partial[(i64)split * (nW + Co) + ((i64)ci * Co + co0 + c) * SS + t] = v;
+    } else if (ci == 0) {
+      const int c = i - COB * SS;
+      if (co0 + c < Co) partial[(i64)split * (nW + Co) + nW + co0 + c] = v;
+    }
+  }
+}
+
+int pick_splits(i64 base_blocks, i64 rows, i64 pixels_per_row) {
+  i64 s = (2048 + base_blocks - 1) / base_blocks;
+  const i64 by_work = (rows * pixels_per_row + 4095) / 4096;
+  if (s > by_work) s = by_work;
+  if (s > rows) s = rows;
+  if (s < 1) s = 1;
+  return (int)s;
+}
+
+constexpr size_t kMaxDynLds = 64 * 1024;
+
+}  // namespace
+
+extern "C" {
+
+int unet_convolve_f32(const float *weights, const float *inputs, float *activations, int64_t act_len,
+                      int N, int k, int Ci, int Co, int Ho, int Wo, int Hi, int Wi, int pad, int stride,
+                      unet_stream_t s) {
+  UNET_REQUIRE(weights && inputs && activations, "unet_convolve_f32: NULL pointer");
+  UNET_REQUIRE(N > 0 && Ci > 0 && Co > 0 && Hi > 0 && Wi > 0 && stride > 0 && pad >= 0,
+               "unet_convolve_f32: need positive sizes");
+  UNET_REQUIRE(k > 0 && (k & 1), "kernel must be square and odd.");
+  UNET_REQUIRE(Ho == (Hi + 2 * pad - k) / stride + 1 && Wo == (Wi + 2 * pad - k) / stride + 1 && Ho > 0 && Wo > 0,
+               "unet_convolve_f32: H_out/W_out (%d,%d) do not match (H_in + 2*padding - k)/stride + 1", Ho, Wo);
+  UNET_REQUIRE(act_len <= 0 || act_len >= (int64_t)N * Co * Ho * Wo,
+               "unet_convolve_f32: activation array too short");
+  UNET_REQUIRE(N <= 65535, "unet_convolve_f32: batch above 65535");
+  const int PH = (TILE - 1) * stride + k;
+  const size_t lds = sizeof(float) * ((((size_t)F_CIB * PH * (PH + 1) + 3) & ~(size_t)3) + (size_t)F_CIB * k * k * F_COB);
+  if (lds > kMaxDynLds)
+    return unet_set_error(UNET_ERR_UNSUPPORTED, "unet_convolve_f32: kernel %d / stride %d needs %zu B of LDS", k,
+                          stride, lds);
+  const int tilesH = (Ho + TILE - 1) / TILE, tilesW = (Wo + TILE - 1) / TILE;
+  dim3 grid((unsigned)(tilesH * tilesW), (unsigned)((Co + F_COB - 1) / F_COB), (unsigned)N);
+  if (k == 3)
+    hipLaunchKernelGGL(conv_fwd_f32_kernel<3>, grid, dim3(256), lds, as_stream(s), weights, inputs, activations,
+                       Ci, Co, Ho, Wo, Hi, Wi, pad, stride, k, tilesW);
+  else if (k == 1)
+    hipLaunchKernelGGL(conv_fwd_f32_kernel<1>, grid, dim3(256), lds, as_stream(s), weights, inputs, activations,
+                       Ci, Co, Ho, Wo, Hi, Wi, pad, stride, k, tilesW);
+  else
+    hipLaunchKernelGGL(conv_fwd_f32_kernel<0>, grid, dim3(256), lds, as_stream(s), weights, inputs, activations,
+                       Ci, Co, Ho, Wo, Hi, Wi, pad, stride, k, tilesW);
+  UNET_LAUNCH_CHECK("conv_fwd_f32_kernel");
+  return UNET_OK;
+}
+
+int unet_convolve_backward_f32(const float *grad_activations, const float *inputs, const float *weights,
+                               float *grad_inputs, float *grad_weights, int N, int k, int Ci, int Co,
+                               int Ho, int Wo, int Hi, int Wi, int pad, int stride, unet_stream_t s) {
+  UNET_REQUIRE(grad_activations && inputs && weights && grad_weights, "unet_convolve_backward_f32: NULL pointer");
+  UNET_REQUIRE(N > 0 && Ci > 0 && Co > 0 && Hi > 0 && Wi > 0 && stride > 0 && pad >= 0,
+               "unet_convolve_backward_f32: need positive sizes");
+  UNET_REQUIRE(k > 0 && (k & 1), "kernel must be square and odd.");
+  UNET_REQUIRE(Ho == (Hi + 2 * pad - k) / stride + 1 && Wo == (Wi + 2 * pad - k) / stride + 1 && Ho > 0 && Wo > 0,
+               "unet_convolve_backward_f32: H_out/W_out (%d,%d) do not match the input geometry", Ho, Wo);
+  UNET_REQUIRE(N <= 65535 && Ci <= 65535, "unet_convolve_backward_f32: batch or C_in above 65535");
+  if (k != 1 && k != 3 && k != 5 && k != 7)
+    return unet_set_error(UNET_ERR_UNSUPPORTED, "unet_convolve_backward_f32: kernel size %d (supported: 1,3,5,7)", k);
+
+  // ---- data gradient
+  if (grad_inputs) {
+    const int PH = (TILE - 1 + k - 1) / stride + 2;
+    const size_t lds = sizeof(float) * ((((size_t)D_COC * PH * (PH + 1) + 3) & ~(size_t)3) + (size_t)D_COC * k * k * D_CIB);
+    if (lds > kMaxDynLds)
+      return unet_set_error(UNET_ERR_UNSUPPORTED, "unet_convolve_backward_f32: needs %zu B of LDS", lds);
+    const int tilesH = (Hi + TILE - 1) / TILE, tilesW = (Wi + TILE - 1) / TILE;
+    dim3 grid((unsigned)(tilesH * tilesW), (unsigned)((Ci + D_CIB - 1) / D_CIB), (unsigned)N);
+    hipLaunchKernelGGL(conv_bwd_data_f32_kernel, grid, dim3(256), lds, as_stream(s), weights, grad_activations,
+                       grad_inputs, Ci, Co, Ho, Wo, Hi, Wi, pad, stride, k, tilesW, PH);
+    UNET_LAUNCH_CHECK("conv_bwd_data_f32_kernel");
+  }
+
+  // ---- weight and bias gradient
+  const i64 nW = (i64)Ci * Co * k * k;
+  const int COB = k == 1 ? 16 : k == 3 ? 8 : k == 5 ? 2 : 1;
+  const int cogroups = (Co + COB - 1) / COB;
+  const int rows = N * Ho;
+  const int splits = pick_splits((i64)Ci * cogroups, rows, Wo);
+  const int rps = (rows + splits - 1) / splits;
+  void *ws;
+  int rc = unet_workspace(&ws, sizeof(float) * (size_t)splits * (size_t)(nW + Co));
+  if (rc) return rc;
+  dim3 grid((unsigned)splits, (unsigned)cogroups, (unsigned)Ci);
+#define LAUNCH_BW(KK_, COB_)                                                                               \
+  hipLaunchKernelGGL((conv_bwd_weight_f32_kernel<KK_, COB_>), grid, dim3(256), 0, as_stream(s), grad_activations, \
+                     inputs, (float *)ws, N, Ci, Co, Ho, Wo, Hi, Wi, pad, stride, rps, nW)
+  if (k == 1) LAUNCH_BW(1, 16);
+  else if (k == 3) LAUNCH_BW(3, 8);
+  else if (k == 5) LAUNCH_BW(5, 2);
+  else LAUNCH_BW(7, 1);
+#undef LAUNCH_BW
+  UNET_LAUNCH_CHECK("conv_bwd_weight_f32_kernel");
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(ew_grid(nW + Co)), dim3(256), 0, as_stream(s), (const float *)ws,
+                     grad_weights, nW + Co, splits);
+  UNET_LAUNCH_CHECK("reduce_partials_kernel");
+  return UNET_OK;
+}
+
+int unet_upsample_f32(const float *inputs, const float *weights, float *activations, int scale, int Ci,
+                      int Co, int Hi, int Wi, int N, unet_stream_t s) {
+  UNET_REQUIRE(inputs && weights && activations, "unet_upsample_f32: NULL pointer");
+  UNET_REQUIRE(N > 0 && Ci > 0 && Co > 0 && Hi > 0 && Wi > 0 && scale > 0, "unet_upsample_f32: need positive sizes");
+  UNET_REQUIRE(N <= 65535, "unet_upsample_f32: batch above 65535");
+  const size_t lds = sizeof(float) * (size_t)U_CIC * scale * scale * U_COB;
+  if (lds > kMaxDynLds) return unet_set_error(UNET_ERR_UNSUPPORTED, "unet_upsample_f32: scale %d too large", scale);
+  const i64 opix = (i64)Hi * scale * Wi * scale;
+  dim3 grid(cdiv_u(opix, 256), (unsigned)((Co + U_COB - 1) / U_COB), (unsigned)N);
+  hipLaunchKernelGGL(upsample_fwd_f32_kernel, grid, dim3(256), lds, as_stream(s), inputs, weights, activations, Ci,
+                     Co, Hi, Wi, scale);
+  UNET_LAUNCH_CHECK("upsample_fwd_f32_kernel");
+  return UNET_OK;
+}
+
+int unet_upsample_backward_f32(const float *grad_activations, const float *inputs, const float *weights,
+                               float *grad_inputs, float *grad_weights, int scale, int Ci, int Co, int Hi,
+                               int Wi, int N, unet_stream_t s) {
+  UNET_REQUIRE(grad_activations && inputs && weights && grad_weights, "unet_upsample_backward_f32: NULL pointer");
+  UNET_REQUIRE(N > 0 && Ci > 0 && Co > 0 && Hi > 0 && Wi > 0 && scale > 0,
+               "unet_upsample_backward_f32: need positive sizes");
+  UNET_REQUIRE(N <= 65535 && Ci <= 65535, "unet_upsample_backward_f32: batch or C_in above 65535");
+  if (scale < 2 || scale > 4)
+    return unet_set_error(UNET_ERR_UNSUPPORTED, "unet_upsample_backward_f32: scale %d (supported: 2,3,4)", scale);
+  if (grad_inputs) {
+    const size_t lds = sizeof(float) * (size_t)UD_COC * scale * scale * UD_CIB;
+    dim3 grid(cdiv_u((i64)Hi * Wi, 256), (unsigned)((Ci + UD_CIB - 1) / UD_CIB), (unsigned)N);
+    hipLaunchKernelGGL(upsample_bwd_data_f32_kernel, grid, dim3(256), lds, as_stream(s), grad_activations, weights,
+                       grad_inputs, Ci, Co, Hi, Wi, scale);
+    UNET_LAUNCH_CHECK("upsample_bwd_data_f32_kernel");
+  }
+  const i64 nW = (i64)Ci * Co * scale * scale;
+  const int COB = scale == 2 ? 8 : scale == 3 ? 4 : 2;
+  const int cogroups = (Co + COB - 1) / COB;
+  const int rows = N * Hi;
+  const int splits = pick_splits((i64)Ci * cogroups, rows, Wi);
+  const int rps = (rows + splits - 1) / splits;
+  void *ws;
+  int rc = unet_workspace(&ws, sizeof(float) * (size_t)splits * (size_t)(nW + Co));
+  if (rc) return rc;
+  dim3 grid((unsigned)splits, (unsigned)cogroups, (unsigned)Ci);
+#define LAUNCH_UW(S_, COB_)                                                                                   \
+  hipLaunchKernelGGL((upsample_bwd_weight_f32_kernel<S_, COB_>), grid, dim3(256), 0, as_stream(s), grad_activations, \
+                     inputs, (float *)ws, N, Ci, Co, Hi, Wi, rps, nW)
+  if (scale == 2) LAUNCH_UW(2, 8);
+  else if (scale == 3) LAUNCH_UW(3, 4);
+  else LAUNCH_UW(4, 2);
+#undef LAUNCH_UW
+  UNET_LAUNCH_CHECK("upsample_bwd_weight_f32_kernel");
+  hipLaunchKernelGGL(reduce_partials_kernel, dim3(ew_grid(nW + Co)), dim3(256), 0, as_stream(s), (const float *)ws,
+                     grad_weights, nW + Co, splits);
+  UNET_LAUNCH_CHECK("reduce_partials_kernel");
+  return UNET_OK;
+}
+
+}  // extern "C"

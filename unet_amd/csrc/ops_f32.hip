@@ -1,0 +1,726 @@
+// fp32 NCHW operator set: one entry point per host function of the reference's
+// operator API (src/cuda_library/cuda_lib.h).  Deterministic (no float
+// atomics), 64-bit indexing, no host synchronisation unless documented.
+//
+// Part 1 of 2: elementwise ops, batch norm, pooling, concat, losses,
+// optimiser.  Convolution and transposed convolution live in conv_f32.hip.
+#include <math.h>
+
+#include "common.h"
+
+#define BN_EPS 1e-8f
+#define BN_MOMENTUM 0.9f
+
+// ---------------------------------------------------------------------------
+// Elementwise kernels.  Vector path: 16 bytes per lane when every pointer is
+// 16-byte aligned; the scalar tail (and the unaligned case) goes element-wise.
+// ---------------------------------------------------------------------------
+namespace {
+
+struct ReluF { __device__ float operator()(float x) const { return x > 0.f ? x : 0.f; } };
+struct SigmF { __device__ float operator()(float x) const { return 1.0f / (1.0f + expf(-x)); } };
+struct ReluBwdF { __device__ float operator()(float dy, float x) const { return x > 0.f ? dy : 0.f; } };
+struct SigmBwdF { __device__ float operator()(float dy, float y) const { return dy * y * (1.0f - y); } };
+struct AddF { __device__ float operator()(float a, float b) const { return a + b; } };
+struct ThreshF {
+  float t;
+  __device__ float operator()(float x) const { return x >= t ? 1.0f : 0.0f; }
+};
+struct ScaleF {
+  float a;
+  __device__ float operator()(float x) const { return x * a; }
+};
+struct SgdF {
+  float lr;
+  __device__ float operator()(float w, float g) const { return w - g * lr; }
+};
+struct DiffLossF {
+  float inv_n;
+  // dLdY = (y - m)/n ; called as f(mask, y)
+  __device__ float operator()(float m, float y) const { return (y - m) * inv_n; }
+};
+
+template <class F>
+__global__ __launch_bounds__(256) void ew1_kernel(const float *a, float *o,
+                                                  i64 n, int vec, F f) {
+  const i64 tid = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  const i64 nth = (i64)gridDim.x * blockDim.x;
+  i64 done = 0;
+  if (vec) {
+    const i64 n4 = n >> 2;
+    const float4 *a4 = reinterpret_cast<const float4 *>(a);
+    float4 *o4 = reinterpret_cast<float4 *>(o);
+    for (i64 i = tid; i < n4; i += nth) {
+      float4 v = a4[i];
+      v.x = f(v.x); v.y = f(v.y); v.z = f(v.z); v.w = f(v.w);
+      o4[i] = v;
+    }
+    done = n4 << 2;
+  }
+  for (i64 i = done + tid; i < n; i += nth) o[i] = f(a[i]);
+}
+
+template <class F>
+__global__ __launch_bounds__(256) void ew2_kernel(const float *a, const float *b, float *o, i64 n,
+                                                  int vec, F f) {
+  const i64 tid = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+  const i64 nth = (i64)gridDim.x * blockDim.x;
+  i64 done = 0;
+  if (vec) {
+    const i64 n4 = n >> 2;
+    const float4 *a4 = reinterpret_cast<const float4 *>(a);
+    const float4 *b4 = reinterpret_cast<const float4 *>(b);
+    float4 *o4 = reinterpret_cast<float4 *>(o);
+    for (i64 i = tid; i < n4; i += nth) {
+      float4 u = a4[i], v = b4[i], r;
+      r.x = f(u.x, v.x); r.y = f(u.y, v.y); r.z = f(u.z, v.z); r.w = f(u.w, v.w);
+      o4[i] = r;
+    }
+    done = n4 << 2;
+  }
+  for (i64 i = done + tid; i < n; i += nth) o[i] = f(a[i], b[i]);
+}
+
+inline int aligned16(const void *p) { return (((uintptr_t)p) & 15) == 0; }
+
+template <class F>
+int launch_ew1(const float *a, float *o, i64 n, F f, unet_stream_t s, const char *name) {
+  UNET_REQUIRE(n >= 0, "%s: negative element count", name);
+  if (n == 0) return UNET_OK;
+  UNET_REQUIRE(a && o, "%s: NULL pointer", name);
+  const int vec = aligned16(a) && aligned16(o);
+  hipLaunchKernelGGL(ew1_kernel<F>, dim3(ew_grid((n + 3) / 4)), dim3(256), 0, as_stream(s), a, o, n, vec, f);
+  UNET_LAUNCH_CHECK(name);
+  return UNET_OK;
+}
+template <class F>
+int launch_ew2(const float *a, const float *b, float *o, i64 n, F f, unet_stream_t s, const char *name) {
+  UNET_REQUIRE(n >= 0, "%s: negative element count", name);
+  if (n == 0) return UNET_OK;
+  UNET_REQUIRE(a && b && o, "%s: NULL pointer", name);
+  const int vec = aligned16(a) && aligned16(b) && aligned16(o);
+  hipLaunchKernelGGL(ew2_kernel<F>, dim3(ew_grid((n + 3) / 4)), dim3(256), 0, as_stream(s), a, b, o, n, vec, f);
+  UNET_LAUNCH_CHECK(name);
+  return UNET_OK;
+}
+
+// ---- Adam -------------------------------------------------------------------
+__global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ w, const float *__restrict__ g,
+                                                   float2 *__restrict__ st, i64 n, float lr, float c1,
+                                                   float c2) {
+  const float b1 = 0.9f, b2 = 0.999f, eps = 1e-8f, wd = 1e-4f;
+  for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (i64)gridDim.x * blockDim.x) {
+    const float gi = g[i];
+    float2 mv = st[i];
+    mv.x = b1 * mv.x + (1.0f - b1) * gi;
+    mv.y = b2 * mv.y + (1.0f - b2) * (gi * gi);
+    st[i] = mv;
+    const float mh = mv.x / c1, vh = mv.y / c2;
+    const float wi = w[i];
+    w[i] = wi - lr * (wd * wi + mh / (sqrtf(vh) + eps));
+  }
+}
+
+// ---- init ---------------------------------------------------------------------
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+__global__ __launch_bounds__(256) void init_he_kernel(float *w, i64 n, float scale, uint64_t seed) {
+  for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (i64)gridDim.x * blockDim.x) {
+    const uint64_t r = splitmix64(seed * 0xD6E8FEB86659FD93ull + (uint64_t)i);
+    // two uniforms in (0,1] and [0,1) from the 64 random bits -> Box-Muller
+    const float u1 = ((float)((r >> 40) + 1)) * (1.0f / 16777216.0f);
+    const float u2 = ((float)((r >> 8) & 0xFFFFFF)) * (1.0f / 16777216.0f);
+    w[i] = sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2) * scale;
+  }
+}
+__global__ __launch_bounds__(256) void init_bn_kernel(float *w, i64 n) {
+  for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (i64)gridDim.x * blockDim.x)
+    w[i] = (i & 1) ? 0.0f : 1.0f;
+}
+__global__ __launch_bounds__(256) void has_nan_kernel(const float *x, i64 n, int *flag) {
+  int bad = 0;
+  for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (i64)gridDim.x * blockDim.x)
+    bad |= (x[i] != x[i]);
+  if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+}
+
+// ---- batch norm ---------------------------------------------------------------
+// Channel c's elements are the N planes x[(n*C+c)*HW .. +HW).  A block reduces
+// slice `s` of the flattened (n, i) range; partial[(c*S+s)*2 + {0,1}].
+template <int MODE>  // 0: (sum x, sum x^2)   1: (sum dy*xhat, sum dy)
+__global__ __launch_bounds__(256) void bn_partial_kernel(const float *__restrict__ x,
+                                                         const float *__restrict__ dy,
+                                                         const float *__restrict__ stats,
+                                                         float *__restrict__ partial, int C, i64 HW,
+                                                         i64 M, int S) {
+  __shared__ float red[2 * 4];
+  const int c = blockIdx.y, s = blockIdx.x;
+  const i64 chunk = (M + S - 1) / S;
+  const i64 j0 = (i64)s * chunk;
+  const i64 j1 = (j0 + chunk < M) ? j0 + chunk : M;
+  float mean = 0.f, inv = 0.f;
+  if (MODE == 1) {
+    mean = stats[2 * c] / (float)M;
+    float var = stats[2 * c + 1] / (float)M - mean * mean;
+    var = var < 0.f ? 0.f : var;
+    inv = 1.0f / sqrtf(var + BN_EPS);
+  }
+  float acc[2] = {0.f, 0.f};
+  for (i64 j = j0 + threadIdx.x; j < j1; j += blockDim.x) {
+    const i64 n = j / HW, i = j - n * HW;
+    const i64 idx = (n * C + c) * HW + i;
+    const float v = x[idx];
+    if (MODE == 0) {
+      acc[0] += v;
+      acc[1] += v * v;
+    } else {
+      const float g = dy[idx];
+      acc[0] += g * ((v - mean) * inv);
+      acc[1] += g;
+    }
+  }
+  block_sum<2>(acc, red);
+  if (threadIdx.x == 0) {
+    partial[((i64)c * S + s) * 2] = acc[0];
+    partial[((i64)c * S + s) * 2 + 1] = acc[1];
+  }
+}
+
+// One thread per channel: sums the S partials in double, writes the pair, and
+// (training forward only) updates the running statistics.
+__global__ void bn_finalize_kernel(const float *__restrict__ partial, float *__restrict__ out2,
+                                   float *__restrict__ running, int C, int S, float M) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double a = 0, b = 0;
+  for (int s = 0; s < S; ++s) {
+    a += partial[((i64)c * S + s) * 2];
+    b += partial[((i64)c * S + s) * 2 + 1];
+  }
+  out2[2 * c] = (float)a;
+  out2[2 * c + 1] = (float)b;
+  if (running) {
+    const float mean = (float)(a / M);
+    float var = (float)(b / M - (a / M) * (a / M));
+    var = var < 0.f ? 0.f : var;
+    running[2 * c] = running[2 * c] * BN_MOMENTUM + (1.0f - BN_MOMENTUM) * mean;
+    running[2 * c + 1] = running[2 * c + 1] * BN_MOMENTUM + (1.0f - BN_MOMENTUM) * var;
+  }
+}
+
+// MODE 0: train normalise (eps outside sqrt, stats = raw sums)
+// MODE 1: inference (eps inside sqrt, stats = [mean,var])
+// MODE 2: backward dx (stats = raw sums, gw = [dgamma,dbeta])
+template <int MODE>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float *__restrict__ x,
+                                                       const float *__restrict__ dy,
+                                                       float *__restrict__ out,
+                                                       const float *__restrict__ gb,
+                                                       const float *__restrict__ stats,
+                                                       const float *__restrict__ gw, int C, i64 HW,
+                                                       i64 planes, float M) {
+  // grid.y strides over planes (n*C + c); grid.x over the plane
+  for (i64 p = blockIdx.y; p < planes; p += gridDim.y) {
+    const int c = (int)(p % C);
+    float a, b;  // out = a*x + b  (MODE 2: see below)
+    float mean, inv, k1 = 0.f, k2 = 0.f;
+    if (MODE == 1) {
+      mean = stats[2 * c];
+      inv = 1.0f / sqrtf(stats[2 * c + 1] + BN_EPS);
+    } else {
+      mean = stats[2 * c] / M;
+      float var = stats[2 * c + 1] / M - mean * mean;
+      var = var < 0.f ? 0.f : var;
+      inv = (MODE == 0) ? 1.0f / (sqrtf(var) + BN_EPS) : 1.0f / sqrtf(var + BN_EPS);
+    }
+    const float gamma = gb[2 * c];
+    if (MODE == 2) {
+      k1 = gw[2 * c + 1] / M;  // dbeta/M
+      k2 = gw[2 * c] / M;      // dgamma/M
+      a = gamma * inv;
+      b = 0.f;
+    } else {
+      a = gamma * inv;
+      b = gb[2 * c + 1] - a * mean;
+    }
+    const float *xp = x + p * HW;
+    float *op = out + p * HW;
+    const float *gp = (MODE == 2) ? dy + p * HW : nullptr;
+    for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < HW; i += (i64)gridDim.x * blockDim.x) {
+      if (MODE == 2) {
+        const float xh = (xp[i] - mean) * inv;
+        op[i] = a * (gp[i] - k1 - xh * k2);
+      } else {
+        op[i] = MODE == 0 ? gamma * ((xp[i] - mean) * inv) + gb[2 * c + 1] : a * xp[i] + b;
+      }
+    }
+  }
+}
+
+inline int bn_splits(i64 M) {
+  i64 s = (M + 16383) / 16384;
+  if (s < 1) s = 1;
+  if (s > 512) s = 512;
+  return (int)s;
+}
+
+// ---- max pool -------------------------------------------------------------------
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float *__restrict__ x,
+                                                          float *__restrict__ y,
+                                                          int32_t *__restrict__ indices,
+                                                          uint8_t *__restrict__ tiemask, i64 total,
+                                                          int H, int W, int Ho, int Wo, int k, int s) {
+  for (i64 o = (i64)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (i64)gridDim.x * blockDim.x) {
+    const int wo = (int)(o % Wo);
+    const i64 t = o / Wo;
+    const int ho = (int)(t % Ho);
+    const i64 plane = t / Ho;
+    const float *xp = x + plane * (i64)H * W;
+    float m = -INFINITY;
+    int arg = -1;
+    for (int i = 0; i < k; ++i) {
+      const int hi = ho * s + i;
+      if (hi >= H) break;
+      for (int j = 0; j < k; ++j) {
+        const int wi = wo * s + j;
+        if (wi >= W) break;
+        const float v = xp[(i64)hi * W + wi];
+        if (arg < 0 || v > m) {
+          m = v;
+          arg = hi * W + wi;
+        }
+      }
+    }
+    y[o] = m;
+    if (indices) indices[o] = arg;
+    if (tiemask) {
+      unsigned bits = 0;
+      for (int i = 0; i < k; ++i)
+        for (int j = 0; j < k; ++j) {
+          const int hi = ho * s + i, wi = wo * s + j, bit = i * k + j;
+          if (hi < H && wi < W && bit < 8 && xp[(i64)hi * W + wi] == m) bits |= 1u << bit;
+        }
+      tiemask[o] = (uint8_t)bits;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void maxpool_bwd_ties_kernel(const float *__restrict__ dy,
+                                                               const float *__restrict__ x,
+                                                               const float *__restrict__ y,
+                                                               float *__restrict__ dx, i64 total, int H,
+                                                               int W, int Ho, int Wo, int s) {
+  for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (i64)gridDim.x * blockDim.x) {
+    const int w = (int)(i % W);
+    const i64 t = i / W;
+    const int h = (int)(t % H);
+    const i64 plane = t / H;
+    const int ho = h / s, wo = w / s;
+    float r = 0.f;
+    if (ho < Ho && wo < Wo) {
+      const i64 o = (plane * Ho + ho) * Wo + wo;
+      r = (x[i] == y[o]) ? dy[o] : 0.f;
+    }
+    dx[i] = r;
+  }
+}
+
+__global__ __launch_bounds__(256) void maxpool_bwd_idx_kernel(const float *__restrict__ dy,
+                                                              const int32_t *__restrict__ indices,
+                                                              float *__restrict__ dx, i64 total, int H,
+                                                              int W, int Ho, int Wo) {
+  // dx was zeroed beforehand; windows do not overlap, so each target element
+  // has a single writer.
+  for (i64 o = (i64)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (i64)gridDim.x * blockDim.x) {
+    const i64 plane = o / ((i64)Ho * Wo);
+    const int idx = indices[o];
+    if (idx >= 0 && idx < H * W) dx[plane * (i64)H * W + idx] = dy[o];
+  }
+}
+
+// ---- concat ----------------------------------------------------------------------
+// dst[n][coff + c][i] <- src[n][c][i]   (dst has Cd channels, src has Cs)
+__global__ __launch_bounds__(256) void chan_copy_kernel(const float *__restrict__ src,
+                                                        float *__restrict__ dst, i64 HW, int Cs,
+                                                        int Cd, int coff, int batch, int to_dst) {
+  const i64 per = (i64)Cs * HW;  // contiguous run per sample
+  const i64 total = per * batch;
+  for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (i64)gridDim.x * blockDim.x) {
+    const i64 n = i / per, r = i - n * per;
+    const i64 j = n * (i64)Cd * HW + (i64)coff * HW + r;
+    if (to_dst)
+      dst[j] = src[i];
+    else
+      dst[i] = src[j];
+  }
+}
+
+// ---- dice ------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void dice_sums_kernel(const float *__restrict__ mask,
+                                                         const float *__restrict__ pred,
+                                                         float *__restrict__ lv, i64 HW) {
+  __shared__ float red[3 * 16];
+  const int n = blockIdx.x;
+  float acc[3] = {0.f, 0.f, 0.f};
+  for (i64 i = threadIdx.x; i < HW; i += blockDim.x) {
+    const float m = mask[n * HW + i], p = pred[n * HW + i];
+    acc[0] += m * p;
+    acc[1] += m;
+    acc[2] += p;
+  }
+  block_sum<3>(acc, red);
+  if (threadIdx.x == 0) {
+    lv[3 * n] = acc[0];
+    lv[3 * n + 1] = acc[1];
+    lv[3 * n + 2] = acc[2];
+  }
+}
+
+__global__ __launch_bounds__(256) void dice_bwd_kernel(const float *__restrict__ mask,
+                                                       const float *__restrict__ lv,
+                                                       float *__restrict__ g, i64 HW, float scale) {
+  const int n = blockIdx.y;
+  const float I = lv[3 * n];
+  const float D = lv[3 * n + 1] + lv[3 * n + 2] + 1e-5f;
+  const float inv = scale * 2.0f / (D * D);
+  for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < HW; i += (i64)gridDim.x * blockDim.x)
+    g[n * HW + i] = (mask[n * HW + i] * D - I) * inv;
+}
+
+// ---- softmax cross entropy ---------------------------------------------------------
+__global__ __launch_bounds__(256) void xent_kernel(const float *__restrict__ logits,
+                                                   const int32_t *__restrict__ target,
+                                                   float *__restrict__ dlogits,
+                                                   float *__restrict__ partial, int C, i64 HW, i64 P,
+                                                   float inv_p) {
+  __shared__ float red[4];
+  float acc[1] = {0.f};
+  for (i64 p = (i64)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (i64)gridDim.x * blockDim.x) {
+    const i64 n = p / HW, i = p - n * HW;
+    const float *lp = logits + n * C * HW + i;
+    float mx = -INFINITY;
+    for (int c = 0; c < C; ++c) mx = fmaxf(mx, lp[(i64)c * HW]);
+    float se = 0.f;
+    for (int c = 0; c < C; ++c) se += expf(lp[(i64)c * HW] - mx);
+    const int t = target[p];
+    acc[0] += logf(se) + mx - lp[(i64)t * HW];
+    if (dlogits) {
+      float *gp = dlogits + n * C * HW + i;
+      const float r = 1.0f / se;
+      for (int c = 0; c < C; ++c)
+        gp[(i64)c * HW] = (expf(lp[(i64)c * HW] - mx) * r - (c == t ? 1.0f : 0.0f)) * inv_p;
+    }
+  }
+  block_sum<1>(acc, red);
+  if (threadIdx.x == 0) partial[blockIdx.x] = acc[0];
+}
+__global__ void xent_finalize_kernel(const float *partial, int nblocks, float *loss, float inv_p) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    double s = 0;
+    for (int i = 0; i < nblocks; ++i) s += partial[i];
+    *loss = (float)(s * inv_p);
+  }
+}
+
+}  // namespace
+
+// ===========================================================================
+extern "C" {
+
+int unet_relu_f32(const float *inputs, float *activations, int64_t n, unet_stream_t s) {
+  return launch_ew1(inputs, activations, n, ReluF(), s, "unet_relu_f32");
+}
+int unet_sigmoid_f32(const float *inputs, float *activations, int64_t n, unet_stream_t s) {
+  return launch_ew1(inputs, activations, n, SigmF(), s, "unet_sigmoid_f32");
+}
+int unet_relu_backward_f32(const float *grad_activations, const float *inputs, float *grad_inputs,
+                           int64_t n, unet_stream_t s) {
+  return launch_ew2(grad_activations, inputs, grad_inputs, n, ReluBwdF(), s, "unet_relu_backward_f32");
+}
+int unet_sigmoid_backward_f32(const float *grad_activations, const float *activations,
+                              float *grad_inputs, int64_t n, unet_stream_t s) {
+  return launch_ew2(grad_activations, activations, grad_inputs, n, SigmBwdF(), s,
+                    "unet_sigmoid_backward_f32");
+}
+int unet_add_b_to_a_f32(float *a, const float *b, int64_t n, unet_stream_t s) {
+  return launch_ew2(a, b, a, n, AddF(), s, "unet_add_b_to_a_f32");
+}
+int unet_threshold_f32(float *x, float threshold, int64_t n, unet_stream_t s) {
+  return launch_ew1(x, x, n, ThreshF{threshold}, s, "unet_threshold_f32");
+}
+int unet_scale_f32(float *x, float alpha, int64_t n, unet_stream_t s) {
+  return launch_ew1(x, x, n, ScaleF{alpha}, s, "unet_scale_f32");
+}
+int unet_update_weights_sgd_f32(float *weights, const float *dLdW, float lr, int64_t n, unet_stream_t s) {
+  return launch_ew2(weights, dLdW, weights, n, SgdF{lr}, s, "unet_update_weights_sgd_f32");
+}
+int unet_difference_loss_backward_f32(const float *mask, const float *y, float *dLdY, int64_t n,
+                                      unet_stream_t s) {
+  UNET_REQUIRE(n > 0, "unet_difference_loss_backward_f32: total_size must be positive");
+  return launch_ew2(mask, y, dLdY, n, DiffLossF{1.0f / (float)n}, s, "unet_difference_loss_backward_f32");
+}
+
+int unet_update_weights_adam_f32(float *weights, const float *dLdW, float *adam_parameters, float lr,
+                                 int64_t n, int t, unet_stream_t s) {
+  UNET_REQUIRE(n >= 0 && t >= 1, "unet_update_weights_adam_f32: need n >= 0 and step t >= 1");
+  if (n == 0) return UNET_OK;
+  UNET_REQUIRE(weights && dLdW && adam_parameters, "unet_update_weights_adam_f32: NULL pointer");
+  const float c1 = (float)(1.0 - pow(0.9, (double)t));
+  const float c2 = (float)(1.0 - pow(0.999, (double)t));
+  hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n)), dim3(256), 0, as_stream(s), weights, dLdW,
+                     reinterpret_cast<float2 *>(adam_parameters), (i64)n, lr, c1, c2);
+  UNET_LAUNCH_CHECK("adam_kernel");
+  return UNET_OK;
+}
+
+int unet_init_he_f32(float *weights, int64_t n, int64_t fan, uint64_t seed, unet_stream_t s) {
+  UNET_REQUIRE(fan > 0, "Can't pass N=0 when initializing with HE or XAVIER");
+  if (n <= 0) return UNET_OK;
+  UNET_REQUIRE(weights, "unet_init_he_f32: NULL pointer");
+  hipLaunchKernelGGL(init_he_kernel, dim3(ew_grid(n)), dim3(256), 0, as_stream(s), weights, (i64)n,
+                     sqrtf(2.0f / (float)fan), seed);
+  UNET_LAUNCH_CHECK("init_he_kernel");
+  return UNET_OK;
+}
+int unet_init_bn_f32(float *weights, int64_t n, unet_stream_t s) {
+  if (n <= 0) return UNET_OK;
+  UNET_REQUIRE(weights, "unet_init_bn_f32: NULL pointer");
+  hipLaunchKernelGGL(init_bn_kernel, dim3(ew_grid(n)), dim3(256), 0, as_stream(s), weights, (i64)n);
+  UNET_LAUNCH_CHECK("init_bn_kernel");
+  return UNET_OK;
+}
+int unet_has_nans_f32(const float *ptr, int64_t n, int *has_nan_host, unet_stream_t s) {
+  UNET_REQUIRE(has_nan_host, "unet_has_nans_f32: NULL result pointer");
+  *has_nan_host = 0;
+  if (!ptr || n <= 0) return UNET_OK;
+  void *ws;
+  int rc = unet_workspace(&ws, 256);
+  if (rc) return rc;
+  UNET_HIP_TRY(hipMemsetAsync(ws, 0, 4, as_stream(s)));
+  hipLaunchKernelGGL(has_nan_kernel, dim3(ew_grid(n)), dim3(256), 0, as_stream(s), ptr, (i64)n, (int *)ws);
+  UNET_LAUNCH_CHECK("has_nan_kernel");
+  UNET_HIP_TRY(hipMemcpyAsync(has_nan_host, ws, 4, hipMemcpyDeviceToHost, as_stream(s)));
+  UNET_HIP_TRY(hipStreamSynchronize(as_stream(s)));
+  return UNET_OK;
+}
+
+// ---- batch norm -----------------------------------------------------------------
+static int bn_check(const char *name, int C, int H, int W, int N) {
+  UNET_REQUIRE(C > 0 && H > 0 && W > 0 && N > 0, "%s: need positive C,H,W,batch (got %d,%d,%d,%d)", name, C, H,
+               W, N);
+  return UNET_OK;
+}
+static dim3 bn_apply_grid(i64 HW, i64 planes) {
+  unsigned gx = (unsigned)((HW + 255) / 256);
+  if (gx > 64) gx = 64;
+  unsigned gy = planes > 16384 ? 16384u : (unsigned)planes;
+  return dim3(gx, gy);
+}
+
+int unet_batch_norm_train_f32(const float *inputs, float *activations, const float *weights,
+                              float *BN_batch_stats, float *BN_running_stats, int C, int H, int W,
+                              int N, unet_stream_t s) {
+  int rc = bn_check("unet_batch_norm_train_f32", C, H, W, N);
+  if (rc) return rc;
+  UNET_REQUIRE(inputs && activations && weights && BN_batch_stats, "unet_batch_norm_train_f32: NULL pointer");
+  const i64 HW = (i64)H * W, M = HW * N;
+  const int S = bn_splits(M);
+  void *ws;
+  rc = unet_workspace(&ws, sizeof(float) * 2 * (size_t)C * S);
+  if (rc) return rc;
+  hipLaunchKernelGGL(bn_partial_kernel<0>, dim3(S, C), dim3(256), 0, as_stream(s), inputs,
+                     (const float *)nullptr, (const float *)nullptr, (float *)ws, C, HW, M, S);
+  UNET_LAUNCH_CHECK("bn_partial_kernel<0>");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv_u(C, 64)), dim3(64), 0, as_stream(s), (const float *)ws,
+                     BN_batch_stats, BN_running_stats, C, S, (float)M);
+  UNET_LAUNCH_CHECK("bn_finalize_kernel");
+  hipLaunchKernelGGL(bn_apply_kernel<0>, bn_apply_grid(HW, (i64)N * C), dim3(256), 0, as_stream(s), inputs,
+                     (const float *)nullptr, activations, weights, (const float *)BN_batch_stats,
+                     (const float *)nullptr, C, HW, (i64)N * C, (float)M);
+  UNET_LAUNCH_CHECK("bn_apply_kernel<0>");
+  return UNET_OK;
+}
+
+int unet_batch_norm_inference_f32(const float *inputs, float *activations, const float *weights,
+                                  const float *BN_stats, int H, int W, int C, int N, unet_stream_t s) {
+  int rc = bn_check("unet_batch_norm_inference_f32", C, H, W, N);
+  if (rc) return rc;
+  UNET_REQUIRE(inputs && activations && weights && BN_stats, "unet_batch_norm_inference_f32: NULL pointer");
+  const i64 HW = (i64)H * W;
+  hipLaunchKernelGGL(bn_apply_kernel<1>, bn_apply_grid(HW, (i64)N * C), dim3(256), 0, as_stream(s), inputs,
+                     (const float *)nullptr, activations, weights, BN_stats, (const float *)nullptr, C, HW,
+                     (i64)N * C, 1.0f);
+  UNET_LAUNCH_CHECK("bn_apply_kernel<1>");
+  return UNET_OK;
+}
+
+int unet_batch_norm_backward_f32(const float *grad_activations, const float *inputs,
+                                 const float *BN_batch_stats, const float *weights, float *grad_inputs,
+                                 float *grad_weights, int C, int H, int W, int N, unet_stream_t s) {
+  int rc = bn_check("unet_batch_norm_backward_f32", C, H, W, N);
+  if (rc) return rc;
+  UNET_REQUIRE(grad_activations && inputs && BN_batch_stats && weights && grad_inputs && grad_weights,
+               "unet_batch_norm_backward_f32: NULL pointer");
+  const i64 HW = (i64)H * W, M = HW * N;
+  const int S = bn_splits(M);
+  void *ws;
+  rc = unet_workspace(&ws, sizeof(float) * 2 * (size_t)C * S);
+  if (rc) return rc;
+  hipLaunchKernelGGL(bn_partial_kernel<1>, dim3(S, C), dim3(256), 0, as_stream(s), inputs, grad_activations,
+                     BN_batch_stats, (float *)ws, C, HW, M, S);
+  UNET_LAUNCH_CHECK("bn_partial_kernel<1>");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv_u(C, 64)), dim3(64), 0, as_stream(s), (const float *)ws,
+                     grad_weights, (float *)nullptr, C, S, (float)M);
+  UNET_LAUNCH_CHECK("bn_finalize_kernel");
+  hipLaunchKernelGGL(bn_apply_kernel<2>, bn_apply_grid(HW, (i64)N * C), dim3(256), 0, as_stream(s), inputs,
+                     grad_activations, grad_inputs, weights, BN_batch_stats, (const float *)grad_weights, C, HW,
+                     (i64)N * C, (float)M);
+  UNET_LAUNCH_CHECK("bn_apply_kernel<2>");
+  return UNET_OK;
+}
+
+// ---- max pool -------------------------------------------------------------------
+int unet_max_pool_indices_f32(const float *inputs, float *activations, int32_t *indices,
+                              uint8_t *tiemask, int N, int stride, int k, int C, int H, int W,
+                              unet_stream_t s) {
+  UNET_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0 && stride > 0 && k > 0,
+               "max pool: need positive batch, channels, H, W, stride, kernel");
+  UNET_REQUIRE(inputs && activations, "max pool: NULL pointer");
+  const int Ho = H / stride, Wo = W / stride;
+  UNET_REQUIRE(Ho > 0 && Wo > 0, "max pool: output would be empty (H=%d W=%d stride=%d)", H, W, stride);
+  const i64 total = (i64)N * C * Ho * Wo;
+  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(ew_grid(total)), dim3(256), 0, as_stream(s), inputs, activations,
+                     indices, tiemask, total, H, W, Ho, Wo, k, stride);
+  UNET_LAUNCH_CHECK("maxpool_fwd_kernel");
+  return UNET_OK;
+}
+int unet_max_pool_f32(const float *inputs, float *activations, int N, int stride, int k, int C, int H,
+                      int W, unet_stream_t s) {
+  return unet_max_pool_indices_f32(inputs, activations, nullptr, nullptr, N, stride, k, C, H, W, s);
+}
+int unet_max_pool_backward_f32(const float *grad_activations, const float *inputs,
+                               const float *activations, float *grad_inputs, int N, int stride, int C,
+                               int H, int W, unet_stream_t s) {
+  UNET_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0 && stride > 0, "max pool backward: need positive sizes");
+  UNET_REQUIRE(grad_activations && inputs && activations && grad_inputs, "max pool backward: NULL pointer");
+  const i64 total = (i64)N * C * H * W;
+  hipLaunchKernelGGL(maxpool_bwd_ties_kernel, dim3(ew_grid(total)), dim3(256), 0, as_stream(s),
+                     grad_activations, inputs, activations, grad_inputs, total, H, W, H / stride, W / stride,
+                     stride);
+  UNET_LAUNCH_CHECK("maxpool_bwd_ties_kernel");
+  return UNET_OK;
+}
+int unet_max_pool_backward_indices_f32(const float *grad_activations, const int32_t *indices,
+                                       float *grad_inputs, int N, int C, int H, int W, int Ho, int Wo,
+                                       unet_stream_t s) {
+  UNET_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0, "max pool backward: need positive sizes");
+  UNET_REQUIRE(grad_activations && indices && grad_inputs, "max pool backward: NULL pointer");
+  UNET_HIP_TRY(hipMemsetAsync(grad_inputs, 0, sizeof(float) * (size_t)N * C * H * W, as_stream(s)));
+  const i64 total = (i64)N * C * Ho * Wo;
+  hipLaunchKernelGGL(maxpool_bwd_idx_kernel, dim3(ew_grid(total)), dim3(256), 0, as_stream(s),
+                     grad_activations, indices, grad_inputs, total, H, W, Ho, Wo);
+  UNET_LAUNCH_CHECK("maxpool_bwd_idx_kernel");
+  return UNET_OK;
+}
+
+// ---- concat ----------------------------------------------------------------------
+int unet_concat_f32(const float *a1, const float *a2, float *out, int N, int64_t HxW, int C1, int C2,
+                    unet_stream_t s) {
+  UNET_REQUIRE(N > 0 && HxW > 0 && C1 >= 0 && C2 >= 0 && C1 + C2 > 0, "concat: bad sizes");
+  UNET_REQUIRE(out && (a1 || C1 == 0) && (a2 || C2 == 0), "concat: NULL pointer");
+  if (C1) {
+    hipLaunchKernelGGL(chan_copy_kernel, dim3(ew_grid((i64)N * C1 * HxW)), dim3(256), 0, as_stream(s), a1, out,
+                       (i64)HxW, C1, C1 + C2, 0, N, 1);
+    UNET_LAUNCH_CHECK("chan_copy_kernel");
+  }
+  if (C2) {
+    hipLaunchKernelGGL(chan_copy_kernel, dim3(ew_grid((i64)N * C2 * HxW)), dim3(256), 0, as_stream(s), a2, out,
+                       (i64)HxW, C2, C1 + C2, C1, N, 1);
+    UNET_LAUNCH_CHECK("chan_copy_kernel");
+  }
+  return UNET_OK;
+}
+int unet_concat_backward_f32(const float *dLdY, float *dLdX, int H, int W, int C1, int C2, int N,
+                             unet_stream_t s) {
+  UNET_REQUIRE(N > 0 && H > 0 && W > 0 && C1 >= 0 && C2 >= 0 && C1 + C2 > 0, "concat backward: bad sizes");
+  UNET_REQUIRE(dLdY && dLdX, "concat backward: NULL pointer");
+  const i64 HW = (i64)H * W;
+  if (C1) {
+    hipLaunchKernelGGL(chan_copy_kernel, dim3(ew_grid((i64)N * C1 * HW)), dim3(256), 0, as_stream(s), dLdY,
+                       dLdX, HW, C1, C1 + C2, 0, N, 0);
+    UNET_LAUNCH_CHECK("chan_copy_kernel");
+  }
+  if (C2) {
+    hipLaunchKernelGGL(chan_copy_kernel, dim3(ew_grid((i64)N * C2 * HW)), dim3(256), 0, as_stream(s), dLdY,
+                       dLdX + (i64)N * C1 * HW, HW, C2, C1 + C2, C1, N, 0);
+    UNET_LAUNCH_CHECK("chan_copy_kernel");
+  }
+  return UNET_OK;
+}
+
+// ---- losses ------------------------------------------------------------------------
+int unet_dice_sums_f32(const float *mask, const float *prediction, int H, int W, int N,
+                       float *loss_values, unet_stream_t s) {
+  UNET_REQUIRE(N > 0 && H > 0 && W > 0, "dice: need positive sizes");
+  UNET_REQUIRE(mask && prediction && loss_values, "dice: NULL pointer");
+  hipLaunchKernelGGL(dice_sums_kernel, dim3(N), dim3(1024), 0, as_stream(s), mask, prediction, loss_values,
+                     (i64)H * W);
+  UNET_LAUNCH_CHECK("dice_sums_kernel");
+  return UNET_OK;
+}
+int unet_dice_score_f32(const float *mask, const float *prediction, int H, int W, int N,
+                        float *loss_values, float *dice_host, unet_stream_t s) {
+  UNET_REQUIRE(dice_host, "dice: NULL result pointer");
+  int rc = unet_dice_sums_f32(mask, prediction, H, W, N, loss_values, s);
+  if (rc) return rc;
+  float *h = new float[3 * (size_t)N];
+  hipError_t e = hipMemcpyAsync(h, loss_values, sizeof(float) * 3 * (size_t)N, hipMemcpyDeviceToHost, as_stream(s));
+  if (e == hipSuccess) e = hipStreamSynchronize(as_stream(s));
+  if (e != hipSuccess) {
+    delete[] h;
+    return unet_set_error(UNET_ERR_HIP, "dice: copy to host failed: %s", hipGetErrorString(e));
+  }
+  float dice = 0.f;
+  for (int i = 0; i < N; ++i) dice += 2.0f * h[3 * i] / (h[3 * i + 1] + h[3 * i + 2] + 1e-5f);
+  delete[] h;
+  *dice_host = dice / (float)N;
+  return UNET_OK;
+}
+int unet_dice_loss_backward_f32(const float *mask, const float *prediction, const float *loss_values,
+                                float *dLdY, int H, int W, int N, float scale, unet_stream_t s) {
+  (void)prediction;
+  UNET_REQUIRE(N > 0 && H > 0 && W > 0, "dice backward: need positive sizes");
+  UNET_REQUIRE(mask && loss_values && dLdY, "dice backward: NULL pointer");
+  const i64 HW = (i64)H * W;
+  unsigned gx = (unsigned)((HW + 255) / 256);
+  if (gx > 256) gx = 256;
+  hipLaunchKernelGGL(dice_bwd_kernel, dim3(gx, N), dim3(256), 0, as_stream(s), mask, loss_values, dLdY, HW,
+                     scale);
+  UNET_LAUNCH_CHECK("dice_bwd_kernel");
+  return UNET_OK;
+}
+int unet_softmax_xent_f32(const float *logits, const int32_t *target, float *dlogits, float *loss_out,
+                          int N, int C, int H, int W, unet_stream_t s) {
+  UNET_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0, "cross entropy: need positive sizes");
+  UNET_REQUIRE(logits && target && loss_out, "cross entropy: NULL pointer");
+  const i64 HW = (i64)H * W, P = HW * N;
+  unsigned nb = ew_grid(P);
+  if (nb > 1024) nb = 1024;
+  void *ws;
+  int rc = unet_workspace(&ws, sizeof(float) * nb);
+  if (rc) return rc;
+  const float inv_p = 1.0f / (float)P;
+  hipLaunchKernelGGL(xent_kernel, dim3(nb), dim3(256), 0, as_stream(s), logits, target, dlogits, (float *)ws, C,
+                     HW, P, inv_p);
+  UNET_LAUNCH_CHECK("xent_kernel");
+  hipLaunchKernelGGL(xent_finalize_kernel, dim3(1), dim3(64), 0, as_stream(s), (const float *)ws, (int)nb,
+                     loss_out, inv_p);
+  UNET_LAUNCH_CHECK("xent_finalize_kernel");
+  return UNET_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,179 @@
+// Runtime half of the C ABI: errors, devices, streams, events, memory.
+#include <stdarg.h>
+#include <string.h>
+
+#include <mutex>
+
+#include "common.h"
+
+static thread_local char g_err[512] = "";
+
+int unet_set_error(int code, const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+// ---- workspace -------------------------------------------------------------
+namespace {
+struct Workspace {
+  void *ptr = nullptr;
+  size_t bytes = 0;
+};
+constexpr int kMaxDevices = 64;
+Workspace g_ws[kMaxDevices];
+std::mutex g_ws_mu;
+}  // namespace
+
+int unet_workspace(void **ptr, size_t bytes) {
+  int dev = 0;
+  UNET_HIP_TRY(hipGetDevice(&dev));
+  UNET_REQUIRE(dev >= 0 && dev < kMaxDevices, "device index %d out of range", dev);
+  std::lock_guard<std::mutex> lk(g_ws_mu);
+  Workspace &w = g_ws[dev];
+  if (w.bytes < bytes) {
+    // Kernels still reading the old block must finish before it is freed.
+    if (w.ptr) {
+      UNET_HIP_TRY(hipDeviceSynchronize());
+      UNET_HIP_TRY(hipFree(w.ptr));
+      w.ptr = nullptr;
+      w.bytes = 0;
+    }
+    size_t want = bytes < (size_t)(8u << 20) ? (size_t)(8u << 20) : bytes + bytes / 2;
+    UNET_HIP_TRY(hipMalloc(&w.ptr, want));
+    w.bytes = want;
+  }
+  *ptr = w.ptr;
+  return UNET_OK;
+}
+
+void unet_workspace_release_all() {
+  std::lock_guard<std::mutex> lk(g_ws_mu);
+  int cur = 0;
+  if (hipGetDevice(&cur) != hipSuccess) return;
+  for (int d = 0; d < kMaxDevices; ++d)
+    if (g_ws[d].ptr) {
+      (void)hipSetDevice(d);
+      (void)hipFree(g_ws[d].ptr);
+      g_ws[d] = Workspace();
+    }
+  (void)hipSetDevice(cur);
+}
+
+extern "C" {
+
+const char *unet_last_error(void) { return g_err; }
+int unet_version(void) { return 100; }
+
+int unet_device_count(int *count) {
+  UNET_REQUIRE(count, "count is NULL");
+  UNET_HIP_TRY(hipGetDeviceCount(count));
+  return UNET_OK;
+}
+int unet_set_device(int device) {
+  UNET_HIP_TRY(hipSetDevice(device));
+  return UNET_OK;
+}
+int unet_get_device(int *device) {
+  UNET_REQUIRE(device, "device is NULL");
+  UNET_HIP_TRY(hipGetDevice(device));
+  return UNET_OK;
+}
+int unet_device_synchronize(void) {
+  UNET_HIP_TRY(hipGetLastError());
+  UNET_HIP_TRY(hipDeviceSynchronize());
+  return UNET_OK;
+}
+int unet_device_reset(void) {
+  UNET_HIP_TRY(hipDeviceSynchronize());
+  unet_workspace_release_all();
+  (void)hipGetLastError();
+  return UNET_OK;
+}
+
+int unet_stream_create(unet_stream_t *stream) {
+  UNET_REQUIRE(stream, "stream is NULL");
+  hipStream_t s;
+  UNET_HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  *stream = (unet_stream_t)s;
+  return UNET_OK;
+}
+int unet_stream_destroy(unet_stream_t stream) {
+  UNET_HIP_TRY(hipStreamDestroy(as_stream(stream)));
+  return UNET_OK;
+}
+int unet_stream_synchronize(unet_stream_t stream) {
+  UNET_HIP_TRY(hipStreamSynchronize(as_stream(stream)));
+  return UNET_OK;
+}
+int unet_event_create(unet_event_t *event) {
+  UNET_REQUIRE(event, "event is NULL");
+  hipEvent_t e;
+  UNET_HIP_TRY(hipEventCreate(&e));
+  *event = (unet_event_t)e;
+  return UNET_OK;
+}
+int unet_event_destroy(unet_event_t event) {
+  UNET_HIP_TRY(hipEventDestroy((hipEvent_t)event));
+  return UNET_OK;
+}
+int unet_event_record(unet_event_t event, unet_stream_t stream) {
+  UNET_HIP_TRY(hipEventRecord((hipEvent_t)event, as_stream(stream)));
+  return UNET_OK;
+}
+int unet_event_synchronize(unet_event_t event) {
+  UNET_HIP_TRY(hipEventSynchronize((hipEvent_t)event));
+  return UNET_OK;
+}
+int unet_stream_wait_event(unet_stream_t stream, unet_event_t event) {
+  UNET_HIP_TRY(hipStreamWaitEvent(as_stream(stream), (hipEvent_t)event, 0));
+  return UNET_OK;
+}
+int unet_event_elapsed_ms(float *ms, unet_event_t start, unet_event_t stop) {
+  UNET_REQUIRE(ms, "ms is NULL");
+  UNET_HIP_TRY(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
+  return UNET_OK;
+}
+
+int unet_malloc(void **ptr, size_t bytes) {
+  UNET_REQUIRE(ptr, "ptr is NULL");
+  *ptr = nullptr;
+  if (bytes == 0) bytes = 4;
+  UNET_HIP_TRY(hipMalloc(ptr, bytes));
+  UNET_HIP_TRY(hipMemset(*ptr, 0, bytes));
+  return UNET_OK;
+}
+int unet_free(void *ptr) {
+  if (ptr) UNET_HIP_TRY(hipFree(ptr));
+  return UNET_OK;
+}
+int unet_host_malloc(void **ptr, size_t bytes) {
+  UNET_REQUIRE(ptr, "ptr is NULL");
+  UNET_HIP_TRY(hipHostMalloc(ptr, bytes ? bytes : 4, hipHostMallocDefault));
+  return UNET_OK;
+}
+int unet_host_free(void *ptr) {
+  if (ptr) UNET_HIP_TRY(hipHostFree(ptr));
+  return UNET_OK;
+}
+int unet_memset(void *ptr, int value, size_t bytes, unet_stream_t stream) {
+  if (bytes) UNET_HIP_TRY(hipMemsetAsync(ptr, value, bytes, as_stream(stream)));
+  return UNET_OK;
+}
+int unet_memcpy_h2d(void *dst, const void *src_host, size_t bytes, unet_stream_t stream) {
+  if (bytes) UNET_HIP_TRY(hipMemcpyAsync(dst, src_host, bytes, hipMemcpyHostToDevice, as_stream(stream)));
+  return UNET_OK;
+}
+int unet_memcpy_d2h(void *dst_host, const void *src, size_t bytes, int blocking, unet_stream_t stream) {
+  if (bytes) UNET_HIP_TRY(hipMemcpyAsync(dst_host, src, bytes, hipMemcpyDeviceToHost, as_stream(stream)));
+  if (blocking) UNET_HIP_TRY(hipStreamSynchronize(as_stream(stream)));
+  return UNET_OK;
+}
+int unet_memcpy_d2d(void *dst, const void *src, size_t bytes, unet_stream_t stream) {
+  if (bytes) UNET_HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, as_stream(stream)));
+  return UNET_OK;
+}
+
+}  // extern "C"
