@@ -120,7 +120,8 @@ def _bn_run(G, capi, x, gb, run_in, dy):
     dx, dgb = G.empty(x.shape), G.empty((2 * c,))
     capi.unet_batch_norm_backward_f32(G.p(dyd), G.p(xd), G.p(stats), G.p(gbd), G.p(dx), G.p(dgb), c, h, w, n, None)
     yi = G.empty(x.shape)
-    capi.unet_batch_norm_inference_f32(G.p(xd), G.p(yi), G.p(gbd), G.p(G.dev(run_in)), h, w, c, n, None)
+    rund = G.dev(run_in)
+    capi.unet_batch_norm_inference_f32(G.p(xd), G.p(yi), G.p(gbd), G.p(rund), h, w, c, n, None)
     return [G.host(t) for t in (y, stats, run, dx, dgb, yi)]
 
 
@@ -241,7 +242,8 @@ def test_concat_layout(G, capi, oracle, golden):
     n, c1, h, w = a.shape
     c2 = b.shape[1]
     out = G.empty((n, c1 + c2, h, w))
-    capi.unet_concat_f32(G.p(G.dev(a)), G.p(G.dev(b)), G.p(out), n, h * w, c1, c2, None)
+    ad, bd = G.dev(a), G.dev(b)
+    capi.unet_concat_f32(G.p(ad), G.p(bd), G.p(out), n, h * w, c1, c2, None)
     assert_exact(G.host(out), golden["cat_y"], what="concat")
     back = G.empty((n * (c1 + c2) * h * w,))
     capi.unet_concat_backward_f32(G.p(out), G.p(back), h, w, c1, c2, n, None)
@@ -288,20 +290,22 @@ def test_dice(G, capi, oracle, golden):
     n, h, w = mask.shape
     lv = G.empty((3 * n,))
     d = ctypes.c_float()
-    capi.unet_dice_score_f32(G.p(G.dev(mask)), G.p(G.dev(pred)), h, w, n, G.p(lv), ctypes.byref(d), None)
+    md, pd = G.dev(mask), G.dev(pred)
+    capi.unet_dice_score_f32(G.p(md), G.p(pd), h, w, n, G.p(lv), ctypes.byref(d), None)
     assert_close(G.host(lv), golden["dice_lv"], what="dice sums")
     assert_close(np.float32(d.value), golden["dice_score"], what="dice score")
     g = G.empty(mask.shape)
-    capi.unet_dice_loss_backward_f32(G.p(G.dev(mask)), G.p(G.dev(pred)), G.p(lv), G.p(g), h, w, n, 1.0, None)
+    capi.unet_dice_loss_backward_f32(G.p(md), G.p(pd), G.p(lv), G.p(g), h, w, n, 1.0, None)
     assert_close(G.host(g), golden["dice_grad_ref"], what="dice backward")
-    capi.unet_dice_loss_backward_f32(G.p(G.dev(mask)), G.p(G.dev(pred)), G.p(lv), G.p(g), h, w, n, -1.0 / n, None)
+    capi.unet_dice_loss_backward_f32(G.p(md), G.p(pd), G.p(lv), G.p(g), h, w, n, -1.0 / n, None)
     assert_close(G.host(g), -golden["dice_grad_ref"] / n, what="dice backward scaled")
     # larger, vs oracle
     rng = np.random.default_rng(5)
     mask = (rng.random((16, 256, 256)) < 0.03).astype(np.float32)
     pred = rng.random((16, 256, 256)).astype(np.float32)
     lv = G.empty((48,))
-    capi.unet_dice_score_f32(G.p(G.dev(mask)), G.p(G.dev(pred)), 256, 256, 16, G.p(lv), ctypes.byref(d), None)
+    md, pd = G.dev(mask), G.dev(pred)
+    capi.unet_dice_score_f32(G.p(md), G.p(pd), 256, 256, 16, G.p(lv), ctypes.byref(d), None)
     d_ref, lv_ref = oracle.dice_score(mask, pred)
     assert_close(G.host(lv), lv_ref, what="dice sums 256x256")
     assert_close(np.float32(d.value), np.float32(d_ref), what="dice 256x256")
@@ -310,19 +314,22 @@ def test_dice(G, capi, oracle, golden):
 def test_difference_and_xent(G, capi, oracle, golden):
     y, m = golden["diff_y"], golden["diff_m"]
     g = G.empty(y.shape)
-    capi.unet_difference_loss_backward_f32(G.p(G.dev(m)), G.p(G.dev(y)), G.p(g), y.size, None)
+    md, yd = G.dev(m), G.dev(y)
+    capi.unet_difference_loss_backward_f32(G.p(md), G.p(yd), G.p(g), y.size, None)
     assert_close(G.host(g), golden["diff_grad"], what="difference loss backward")
     logits, tgt = golden["xent_logits"], golden["xent_target"]
     n, c, h, w = logits.shape
     gl, loss = G.empty(logits.shape), G.empty((1,))
-    capi.unet_softmax_xent_f32(G.p(G.dev(logits)), G.p(G.dev(tgt)), G.p(gl), G.p(loss), n, c, h, w, None)
+    ld, td = G.dev(logits), G.dev(tgt)
+    capi.unet_softmax_xent_f32(G.p(ld), G.p(td), G.p(gl), G.p(loss), n, c, h, w, None)
     assert_close(G.host(loss)[0], golden["xent_loss"], what="cross entropy")
     assert_close(G.host(gl), golden["xent_grad"], what="cross entropy grad")
     rng = np.random.default_rng(9)
     logits = (rng.standard_normal((3, 7, 33, 20)) * 3).astype(np.float32)
     tgt = rng.integers(0, 7, (3, 33, 20)).astype(np.int32)
     gl = G.empty(logits.shape)
-    capi.unet_softmax_xent_f32(G.p(G.dev(logits)), G.p(G.dev(tgt)), G.p(gl), G.p(loss), 3, 7, 33, 20, None)
+    ld, td = G.dev(logits), G.dev(tgt)
+    capi.unet_softmax_xent_f32(G.p(ld), G.p(td), G.p(gl), G.p(loss), 3, 7, 33, 20, None)
     l_ref, g_ref = oracle.softmax_xent(logits, tgt)
     assert_close(G.host(loss)[0], np.float32(l_ref), what="cross entropy vs oracle")
     assert_close(G.host(gl), g_ref, what="cross entropy grad vs oracle")
@@ -332,15 +339,17 @@ def test_adam(G, capi, oracle, golden):
     w = G.dev(golden["adam_w0"])
     st = torch.zeros(2 * w.numel(), device=G.DEV)
     for t, g in enumerate(golden["adam_grads"], start=1):
-        capi.unet_update_weights_adam_f32(G.p(w), G.p(G.dev(g)), G.p(st), 0.01, w.numel(), t, None)
+        gd = G.dev(g)
+        capi.unet_update_weights_adam_f32(G.p(w), G.p(gd), G.p(st), 0.01, w.numel(), t, None)
+        torch.cuda.synchronize()
     assert_close(G.host(w), golden["adam_w3"], what="adam weights")
     assert_close(G.host(st), golden["adam_state3"], what="adam state")
     rng = np.random.default_rng(11)
     n = 100003
     w0, g0 = rng.standard_normal(n).astype(np.float32), rng.standard_normal(n).astype(np.float32)
     st0 = np.abs(rng.standard_normal(2 * n)).astype(np.float32) * 0.01
-    wd, sd = G.dev(w0), G.dev(st0)
-    capi.unet_update_weights_adam_f32(G.p(wd), G.p(G.dev(g0)), G.p(sd), 1e-3, n, 7, None)
+    wd, sd, gd = G.dev(w0), G.dev(st0), G.dev(g0)
+    capi.unet_update_weights_adam_f32(G.p(wd), G.p(gd), G.p(sd), 1e-3, n, 7, None)
     w_ref, st_ref = oracle.adam(w0, g0, st0, 1e-3, 7)
     assert_close(G.host(wd), w_ref, rtol=1e-5, what="adam vs oracle")
     assert_close(G.host(sd), st_ref, rtol=1e-5, what="adam state vs oracle")
