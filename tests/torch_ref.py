@@ -1,0 +1,180 @@
+"""PyTorch-CPU (float64) restatement of a `neural_net` graph, used as the
+network-level oracle (the reference names PyTorch-CPU as its oracle in
+test/torch_compare.py:109-146).  Test infrastructure only.
+
+A graph is a list of (kind, shape, parents, activation) tuples with the same
+field orders as neural_net.LayerDesc; `params` is the flat fp32 parameter
+vector in the module's layout: per CONV/UPSAMPLING layer
+[weights (C_in,C_out,k,k) | biases (C_out) | gamma0,beta0,gamma1,beta1,...].
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+BN_EPS = 1e-8
+
+
+def main_py_graph(h=256, w=256, cin=3, f1=64):
+    """The 16-layer graph of the reference's main.py:187-224 (3 down / 3 up,
+    single conv per stage), scalable for tests."""
+    f2, f3, f4 = 2 * f1, 4 * f1, 8 * f1
+    h2, h3, h4, w2, w3, w4 = h // 2, h // 4, h // 8, w // 2, w // 4, w // 8
+    return [
+        ("conv", [h, w, cin, f1, 3, 1, 1], [], "relu"),      # 0
+        ("pool", [f1, h, w, 2, 2], [0], None),               # 1
+        ("conv", [h2, w2, f1, f2, 3, 1, 1], [1], "relu"),    # 2
+        ("pool", [f2, h2, w2, 2, 2], [2], None),             # 3
+        ("conv", [h3, w3, f2, f3, 3, 1, 1], [3], "relu"),    # 4
+        ("pool", [f3, h3, w3, 2, 2], [4], None),             # 5
+        ("conv", [h4, w4, f3, f4, 3, 1, 1], [5], "relu"),    # 6
+        ("up", [h4, w4, f4, f3, 2], [6], None),              # 7
+        ("concat", [], [4, 7], None),                        # 8
+        ("conv", [h3, w3, f4, f2, 3, 1, 1], [8], "relu"),    # 9
+        ("up", [h3, w3, f2, f2, 2], [9], None),              # 10
+        ("concat", [], [2, 10], None),                       # 11
+        ("conv", [h2, w2, f3, f1, 3, 1, 1], [11], "relu"),   # 12
+        ("up", [h2, w2, f1, f1, 2], [12], None),             # 13
+        ("concat", [], [0, 13], None),                       # 14
+        ("conv", [h, w, f2, 1, 3, 1, 1], [14], "sigmoid"),   # 15
+    ]
+
+
+def unet_graph(h=256, w=256, cin=3, base=64, depth=4, double_conv=True):
+    """Classic U-Net: `depth` down / `depth` up levels, (double) 3x3 conv + BN +
+    ReLU per stage, 2x2 max pool, 2x2 transposed-conv upsampling, skip concat,
+    final 3x3 conv to one sigmoid channel."""
+    g = []
+
+    def conv(hh, ww, ci, co, parent, act="relu"):
+        g.append(("conv", [hh, ww, ci, co, 3, 1, 1], [] if parent is None else [parent], act))
+        return len(g) - 1
+
+    def stage(hh, ww, ci, co, parent):
+        i = conv(hh, ww, ci, co, parent)
+        if double_conv:
+            i = conv(hh, ww, co, co, i)
+        return i
+
+    skips = []
+    cur, c, hh, ww = None, cin, h, w
+    for d in range(depth):
+        co = base << d
+        cur = stage(hh, ww, c, co, cur)
+        skips.append((cur, co, hh, ww))
+        g.append(("pool", [co, hh, ww, 2, 2], [cur], None))
+        cur, c, hh, ww = len(g) - 1, co, hh // 2, ww // 2
+    cur = stage(hh, ww, c, base << depth, cur)
+    c = base << depth
+    for d in reversed(range(depth)):
+        skip, co, sh, sw = skips[d]
+        g.append(("up", [hh, ww, c, co, 2], [cur], None))
+        up = len(g) - 1
+        g.append(("concat", [], [skip, up], None))
+        cur = stage(sh, sw, 2 * co, co, len(g) - 1)
+        c, hh, ww = co, sh, sw
+    conv(hh, ww, c, 1, cur, "sigmoid")
+    return g
+
+
+def to_layer_descs(nn, graph):
+    kinds = {"conv": nn.LayerType.CONV_LAYER, "pool": nn.LayerType.MAX_POOL_LAYER,
+             "up": nn.LayerType.UPSAMPLING_LAYER, "concat": nn.LayerType.CONCAT_LAYER}
+    out = []
+    for kind, shape, parents, act in graph:
+        if act == "sigmoid":
+            out.append(nn.LayerDesc(kinds[kind], shape, parents, nn.ActivationType.SIGMOID))
+        else:
+            out.append(nn.LayerDesc(kinds[kind], shape, parents))
+    return out
+
+
+def param_count(graph):
+    n = 0
+    for kind, s, _, _ in graph:
+        if kind == "conv":
+            n += s[2] * s[3] * s[4] * s[4] + s[3] + 2 * s[3]
+        elif kind == "up":
+            n += s[2] * s[3] * s[4] * s[4] + s[3] + 2 * s[3]
+    return n
+
+
+def split_params(graph, flat):
+    """-> list (per layer) of dicts of torch leaf tensors (float64, requires_grad) or None."""
+    flat = torch.as_tensor(np.asarray(flat, dtype=np.float64))
+    out, off = [], 0
+    for kind, s, _, _ in graph:
+        if kind in ("conv", "up"):
+            ci, co, k = s[2], s[3], s[4]
+            nw = ci * co * k * k
+            d = {
+                "w": flat[off:off + nw].reshape(ci, co, k, k).clone().requires_grad_(True),
+                "b": flat[off + nw:off + nw + co].clone().requires_grad_(True),
+                "gamma": flat[off + nw + co:off + nw + 3 * co:2].clone().requires_grad_(True),
+                "beta": flat[off + nw + co + 1:off + nw + 3 * co:2].clone().requires_grad_(True),
+            }
+            off += nw + 3 * co
+            out.append(d)
+        else:
+            out.append(None)
+    assert off == flat.numel(), (off, flat.numel())
+    return out
+
+
+def flat_grads(graph, params):
+    parts = []
+    for p in params:
+        if p is None:
+            continue
+        parts += [p["w"].grad.reshape(-1), p["b"].grad.reshape(-1),
+                  torch.stack([p["gamma"].grad, p["beta"].grad], dim=1).reshape(-1)]
+    return torch.cat(parts).numpy()
+
+
+def forward(graph, params, x, training=True, running=None):
+    """x float64 [N,C,H,W] -> list of per-layer activations.  `running`
+    (optional list of [mean,var] interleaved arrays per layer) is used when
+    training=False."""
+    acts = []
+    for i, (kind, s, parents, act) in enumerate(graph):
+        inp = x if not parents else acts[parents[0]]
+        if kind in ("conv", "up"):
+            p = params[i]
+            if kind == "conv":
+                z = F.conv2d(inp, p["w"].permute(1, 0, 2, 3), p["b"], stride=s[6], padding=s[5])
+            else:
+                z = F.conv_transpose2d(inp, p["w"], p["b"], stride=s[4])
+            if training:
+                y = F.batch_norm(z, None, None, p["gamma"], p["beta"], training=True, eps=BN_EPS)
+            else:
+                r = torch.as_tensor(np.asarray(running[i], dtype=np.float64))
+                y = F.batch_norm(z, r[0::2], r[1::2], p["gamma"], p["beta"], training=False, eps=BN_EPS)
+            acts.append(torch.sigmoid(y) if act == "sigmoid" else torch.relu(y))
+        elif kind == "pool":
+            acts.append(F.max_pool2d(inp, s[3], s[4]))
+        elif kind == "concat":
+            acts.append(torch.cat([acts[parents[0]], acts[parents[1]]], dim=1))
+        else:
+            raise ValueError(kind)
+    return acts
+
+
+def dice_loss(pred, mask):
+    """L = 1 - mean_n 2*I/(sum m + sum p + 1e-5); pred [N,1,H,W], mask [N,H,W]."""
+    p = pred[:, 0]
+    inter = (p * mask).sum(dim=(1, 2))
+    d = mask.sum(dim=(1, 2)) + p.sum(dim=(1, 2)) + 1e-5
+    return 1.0 - (2.0 * inter / d).mean()
+
+
+def difference_loss(pred, mask):
+    return 0.5 * ((pred[:, 0] - mask) ** 2).mean()
+
+
+def adam_step(flat_params, flat_grad, state, lr, t):
+    """The module's optimiser: Adam beta (.9,.999), eps 1e-8, decoupled weight
+    decay 1e-4 (src/cuda_library/cuda_ops.cu:405-441).  float64 numpy."""
+    m, v = state
+    m[:] = 0.9 * m + 0.1 * flat_grad
+    v[:] = 0.999 * v + 0.001 * flat_grad * flat_grad
+    mh, vh = m / (1 - 0.9 ** t), v / (1 - 0.999 ** t)
+    return flat_params - lr * (1e-4 * flat_params + mh / (np.sqrt(vh) + 1e-8))

@@ -1,0 +1,38 @@
+// Descriptor types of the Python-facing API.  Names and enumerator order follow
+// the reference (src/neural_net_implementation/layer.h:21-44) because they are
+// part of the module's surface (src/bindings/net.cpp:49-87).
+#pragma once
+#include <vector>
+
+enum Layer_type {
+  CONV_LAYER,
+  BN_LAYER,
+  MAX_POOL_LAYER,
+  ATTENTION_LAYER,
+  FC_LAYER,
+  CONCAT_LAYER,
+  UPSAMPLING_LAYER,
+};
+
+enum Activation_type { ReLU, SOFTMAX, NONE, TANH, SIGMOID, LEAKY_ReLU };
+
+enum class LossFunction {
+  kDiceLoss,
+  kDifferenceLoss,
+};
+
+// descriptor field orders (layer.h:426-432, 461-465, 580-584):
+//   CONV_LAYER        [H_in, W_in, C_in, C_out, kernel, padding, stride]
+//   MAX_POOL_LAYER    [C, H, W, kernel, stride]
+//   UPSAMPLING_LAYER  [H_in, W_in, C_in, C_out, scale]
+//   CONCAT_LAYER      []   (shape from the two parents; first parent = skip)
+struct LayerDesc {
+  Layer_type type;
+  std::vector<int> descriptor;
+  std::vector<int> parents;
+  Activation_type activation;
+  double leaky_const;
+  LayerDesc(const Layer_type &t, const std::vector<int> &d, const std::vector<int> &p,
+            const Activation_type &a, double lc)
+      : type(t), descriptor(d), parents(p), activation(a), leaky_const(lc) {}
+};

@@ -1,0 +1,669 @@
+// Network engine: the layer graph behind `neural_net.NeuralNet`.
+//
+// Host-only C++ (no HIP headers): every device operation goes through the C ABI
+// of libunet_hip.so (include/unet_hip.h).  It plays the role of the reference's
+// class NN (src/neural_net_implementation/neural_net.h:23-265) and class Layer
+// (src/neural_net_implementation/layer.h:46-617), redesigned:
+//   - layers are kept in creation order, which the parent-index rule makes a
+//     topological order, so forward is a loop and backward the reverse loop
+//     (the reference recurses from the final layer);
+//   - all parameters live in ONE flat buffer, all gradients in another, Adam
+//     state in a third: one optimiser launch per step and contiguous buckets
+//     for the data-parallel all-reduce;
+//   - every buffer is allocated once per batch size; no malloc/free, no host
+//     synchronisation and no device-to-host copy inside a training step.
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+#include <set>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "layer_desc.h"
+#include "unet_hip.h"
+
+namespace unet {
+
+inline void check(int rc, const char *what) {
+  if (rc != UNET_OK) {
+    std::stringstream ss;
+    ss << what << ": " << unet_last_error();
+    throw std::runtime_error(ss.str());
+  }
+}
+#define UNET_CALL(expr) ::unet::check((expr), #expr)
+
+inline int64_t shape_size(const std::vector<int> &shape) {
+  int64_t s = 1;
+  for (int d : shape) s *= d;
+  return s;
+}
+
+// Owning device allocation (zero-filled).
+class DeviceBuffer {
+ public:
+  DeviceBuffer() = default;
+  DeviceBuffer(const DeviceBuffer &) = delete;
+  DeviceBuffer &operator=(const DeviceBuffer &) = delete;
+  DeviceBuffer(DeviceBuffer &&o) noexcept : ptr_(o.ptr_), bytes_(o.bytes_) {
+    o.ptr_ = nullptr;
+    o.bytes_ = 0;
+  }
+  DeviceBuffer &operator=(DeviceBuffer &&o) noexcept {
+    if (this != &o) {
+      release();
+      ptr_ = o.ptr_;
+      bytes_ = o.bytes_;
+      o.ptr_ = nullptr;
+      o.bytes_ = 0;
+    }
+    return *this;
+  }
+  ~DeviceBuffer() { release(); }
+  void ensure(size_t bytes) {
+    if (bytes <= bytes_) return;
+    release();
+    UNET_CALL(unet_malloc(&ptr_, bytes));
+    bytes_ = bytes;
+  }
+  void release() {
+    if (ptr_) unet_free(ptr_);
+    ptr_ = nullptr;
+    bytes_ = 0;
+  }
+  float *f32() const { return static_cast<float *>(ptr_); }
+  void *raw() const { return ptr_; }
+  size_t bytes() const { return bytes_; }
+
+ private:
+  void *ptr_ = nullptr;
+  size_t bytes_ = 0;
+};
+
+struct Node {
+  Layer_type type;
+  Activation_type activation = NONE;
+  std::vector<int> parents;
+  int num_children = 0;
+  // geometry (per sample)
+  int in_c = 0, in_h = 0, in_w = 0, out_c = 0, out_h = 0, out_w = 0;
+  int kernel = 0, padding = 0, stride = 1;
+  int c1 = 0, c2 = 0;  // concat: channels of the two parents
+  std::vector<int> input_shape, output_shape;
+  // parameters: slice [param_off, param_off + num_wb + num_bn) of the flat
+  // buffers, laid out [weights | biases | gamma0,beta0,...] like the
+  // reference's per-layer dLdW (layer.h:274)
+  int64_t num_wb = 0, num_bn = 0, param_off = 0;
+  int64_t fan = 0;
+  DeviceBuffer running;      // [mean,var] interleaved
+  DeviceBuffer batch_stats;  // raw sums
+  // fp32 activations (NCHW): conv/tconv output, BN output, activation
+  DeviceBuffer z, bn, act;
+  DeviceBuffer grad_out;  // dL/d(act)
+  bool grad_seen = false;
+  int64_t in_elems() const { return (int64_t)in_c * in_h * in_w; }
+  int64_t out_elems() const { return (int64_t)out_c * out_h * out_w; }
+  bool has_params() const { return type == CONV_LAYER || type == UPSAMPLING_LAYER; }
+};
+
+class Net {
+ public:
+  Net() = default;
+  ~Net() {
+    for (void *e : bucket_events_) unet_event_destroy(e);
+  }
+
+  // ---- graph construction (neural_net.h:72-120, layer.h:412-616) ----------
+  void create(const std::vector<LayerDesc> &desc, LossFunction loss) {
+    if (!nodes_.empty()) throw std::runtime_error("create() was already called on this network");
+    if (desc.empty()) throw std::runtime_error("your network does not have a single output node");
+    loss_ = loss;
+    nodes_.reserve(desc.size());
+    for (size_t i = 0; i < desc.size(); ++i) {
+      for (int p : desc[i].parents) {
+        if (p < 0 || p >= (int)i) {
+          std::stringstream ss;
+          ss << "invalid parent index: " << p << " is less than 0 or greater than current index " << i;
+          throw std::runtime_error(ss.str());
+        }
+      }
+      nodes_.emplace_back();
+      try {
+        init_node(nodes_.back(), desc[i]);
+      } catch (...) {
+        nodes_.clear();
+        throw;
+      }
+    }
+    std::set<int> is_parent;
+    for (const LayerDesc &d : desc)
+      for (int p : d.parents) is_parent.insert(p);
+    if (is_parent.size() != desc.size() - 1) {
+      nodes_.clear();
+      throw std::runtime_error("your network does not have a single output node");
+    }
+    final_ = -1;
+    for (size_t i = 0; i < desc.size(); ++i)
+      if (!is_parent.count((int)i)) final_ = (int)i;
+    for (const LayerDesc &d : desc)
+      for (int p : d.parents) nodes_[p].num_children++;
+    // input geometry = the (first) parentless layer
+    for (const Node &n : nodes_)
+      if (n.parents.empty()) {
+        in_c_ = n.in_c;
+        in_h_ = n.in_h;
+        in_w_ = n.in_w;
+        break;
+      }
+    for (const Node &n : nodes_)
+      if (n.parents.empty() && (n.in_c != in_c_ || n.in_h != in_h_ || n.in_w != in_w_))
+        throw std::runtime_error("all input layers must take the same [C,H,W] input");
+    // parameters
+    total_params_ = 0;
+    for (Node &n : nodes_) {
+      n.param_off = total_params_;
+      total_params_ += n.num_wb + n.num_bn;
+    }
+    params_.ensure(sizeof(float) * (size_t)std::max<int64_t>(total_params_, 1));
+    grads_.ensure(sizeof(float) * (size_t)std::max<int64_t>(total_params_, 1));
+    adam_.ensure(sizeof(float) * 2 * (size_t)std::max<int64_t>(total_params_, 1));
+    init_parameters(seed_);
+    if (verbose_)
+      for (const Node &n : nodes_)
+        if (n.has_params()) std::cout << "add params: " << n.num_wb + n.num_bn << std::endl;
+  }
+
+  // He(fan-in) weights, zero biases, gamma = 1, beta = 0, running mean 0 /
+  // var 1.  (The reference's BN initialiser never runs, leaving gamma = 0:
+  // layer.h:445-447 with cuda_ops.cu:41,52.)
+  void init_parameters(uint64_t seed) {
+    seed_ = seed;
+    UNET_CALL(unet_memset(params_.raw(), 0, params_.bytes(), stream_));
+    UNET_CALL(unet_memset(adam_.raw(), 0, adam_.bytes(), stream_));
+    step_count_ = 0;
+    uint64_t layer_id = 0;
+    for (Node &n : nodes_) {
+      ++layer_id;
+      if (!n.has_params()) continue;
+      float *w = params_.f32() + n.param_off;
+      UNET_CALL(unet_init_he_f32(w, n.num_wb - n.out_c, n.fan, seed * 1000003ull + layer_id, stream_));
+      UNET_CALL(unet_init_bn_f32(w + n.num_wb, n.num_bn, stream_));
+      n.running.ensure(sizeof(float) * (size_t)n.num_bn);
+      n.batch_stats.ensure(sizeof(float) * (size_t)n.num_bn);
+      // running [mean,var] = [0,1]: var sits at the odd slots
+      UNET_CALL(unet_init_bn_f32(n.running.f32() + 1, n.num_bn - 1, stream_));
+      UNET_CALL(unet_memset(n.running.raw(), 0, sizeof(float), stream_));
+    }
+    params_dirty_ = true;
+  }
+
+  // ---- training step pieces (device pointers, nothing synchronises) --------
+  // images [batch, C, H, W] fp32, masks [batch, H_out, W_out] fp32, on device.
+  void forward_device(const float *images, int batch, bool inference) {
+    if (batch < 1) throw std::runtime_error("Batch size must be greater than 0");
+    require_created();
+    ensure_batch(batch);
+    for (Node &n : nodes_) forward_node(n, images, batch, inference);
+  }
+
+  // Sums for the loss of the current forward output; fills loss_values_.
+  void loss_forward_device(const float *masks, int batch) {
+    Node &f = nodes_[final_];
+    if (loss_ == LossFunction::kDiceLoss)
+      UNET_CALL(unet_dice_sums_f32(masks, f.act.f32(), f.out_h, f.out_w, batch, loss_values_.f32(), stream_));
+  }
+
+  void backward_device(const float *images, const float *masks, int batch) {
+    require_created();
+    Node &f = nodes_[final_];
+    if (f.out_c != 1) throw std::runtime_error("the loss functions need a final layer with one output channel");
+    for (Node &n : nodes_) n.grad_seen = false;
+    next_bucket_ = 0;
+    // loss gradient -> final layer's grad_out
+    if (loss_ == LossFunction::kDiceLoss) {
+      // L = 1 - mean_n dice_n  =>  dL/dp = -(1/N) * 2(mD - I)/D^2
+      UNET_CALL(unet_dice_loss_backward_f32(masks, f.act.f32(), loss_values_.f32(), f.grad_out.f32(), f.out_h,
+                                            f.out_w, batch, -1.0f / (float)batch, stream_));
+    } else {
+      UNET_CALL(unet_difference_loss_backward_f32(masks, f.act.f32(), f.grad_out.f32(),
+                                                  (int64_t)batch * f.out_h * f.out_w, stream_));
+    }
+    f.grad_seen = true;
+    for (int i = (int)nodes_.size() - 1; i >= 0; --i) {
+      backward_node(nodes_[i], images, batch);
+      record_finished_buckets(i);
+    }
+  }
+
+  // One Adam step over every parameter (cuda_ops.cu:405-471 semantics, one
+  // step counter for the whole network).
+  void step_device(float learning_rate) {
+    ++step_count_;
+    UNET_CALL(unet_update_weights_adam_f32(params_.f32(), grads_.f32(), adam_.f32(), learning_rate,
+                                           total_params_, step_count_, stream_));
+    params_dirty_ = true;
+  }
+
+  // ---- host-facing helpers ----------------------------------------------------
+  // Copies a batch from host memory and runs forward (+ loss sums, backward,
+  // step when training).  Returns nothing; results are read with the getters.
+  void train_batch_host(const float *images, const float *masks, int batch, float lr, bool do_step) {
+    ensure_batch(batch);
+    const size_t ib = sizeof(float) * (size_t)batch * in_c_ * in_h_ * in_w_;
+    const Node &f = nodes_[final_];
+    const size_t mb = sizeof(float) * (size_t)batch * f.out_h * f.out_w;
+    UNET_CALL(unet_memcpy_h2d(in_images_.raw(), images, ib, stream_));
+    UNET_CALL(unet_memcpy_h2d(in_masks_.raw(), masks, mb, stream_));
+    forward_device(in_images_.f32(), batch, false);
+    loss_forward_device(in_masks_.f32(), batch);
+    backward_device(in_images_.f32(), in_masks_.f32(), batch);
+    if (do_step) step_device(lr);
+  }
+
+  // Loss of the last batch (synchronises): Dice: 1 - mean dice; difference:
+  // 0.5 * mean (y - m)^2.
+  float last_loss(int batch, float *dice_out = nullptr) {
+    const Node &f = nodes_[final_];
+    sync();
+    if (loss_ == LossFunction::kDiceLoss) {
+      std::vector<float> lv(3 * (size_t)batch);
+      UNET_CALL(unet_memcpy_d2h(lv.data(), loss_values_.raw(), sizeof(float) * lv.size(), 1, stream_));
+      float dice = 0.f;
+      for (int i = 0; i < batch; ++i) dice += 2.0f * lv[3 * i] / (lv[3 * i + 1] + lv[3 * i + 2] + 1e-5f);
+      dice /= (float)batch;
+      if (dice_out) *dice_out = dice;
+      return 1.0f - dice;
+    }
+    const size_t n = (size_t)batch * f.out_h * f.out_w;
+    std::vector<float> y(n), m(n);
+    UNET_CALL(unet_memcpy_d2h(y.data(), f.act.raw(), sizeof(float) * n, 1, stream_));
+    UNET_CALL(unet_memcpy_d2h(m.data(), in_masks_.raw(), sizeof(float) * n, 1, stream_));
+    double s = 0;
+    for (size_t i = 0; i < n; ++i) s += 0.5 * (double)(y[i] - m[i]) * (y[i] - m[i]);
+    if (dice_out) *dice_out = 0.f;
+    return (float)(s / (double)n);
+  }
+
+  void sync() { UNET_CALL(unet_stream_synchronize(stream_)); }
+
+  void copy_params_to_host(float *dst) {
+    UNET_CALL(unet_memcpy_d2h(dst, params_.raw(), sizeof(float) * (size_t)total_params_, 1, stream_));
+  }
+  void copy_params_from_host(const float *src) {
+    UNET_CALL(unet_memcpy_h2d(params_.raw(), src, sizeof(float) * (size_t)total_params_, stream_));
+    sync();
+    params_dirty_ = true;
+  }
+  void copy_grads_to_host(float *dst) {
+    UNET_CALL(unet_memcpy_d2h(dst, grads_.raw(), sizeof(float) * (size_t)total_params_, 1, stream_));
+  }
+  void copy_output_to_host(int layer, float *dst, int batch) {
+    const Node &n = nodes_.at(layer);
+    UNET_CALL(unet_memcpy_d2h(dst, n.act.raw(), sizeof(float) * (size_t)batch * n.out_elems(), 1, stream_));
+  }
+  void copy_running_stats_to_host(int layer, float *dst) {
+    const Node &n = nodes_.at(layer);
+    UNET_CALL(unet_memcpy_d2h(dst, n.running.raw(), sizeof(float) * (size_t)n.num_bn, 1, stream_));
+  }
+
+  // ---- data-parallel support ---------------------------------------------------
+  // Gradient buckets: contiguous slices of the flat gradient buffer, cut at
+  // layer boundaries, numbered in the order backward completes them (last layer
+  // first).  After backward_device() bucket b is final once its event fires.
+  void set_bucket_bytes(int64_t bytes) {
+    bucket_bytes_ = bytes;
+    buckets_.clear();
+  }
+  struct Bucket {
+    int64_t offset, count;  // in floats
+    int first_layer;        // the bucket is final when this layer's backward is done
+  };
+  const std::vector<Bucket> &buckets() {
+    if (buckets_.empty() && total_params_ > 0) {
+      int64_t end = total_params_;
+      int64_t cur = 0;
+      for (int i = (int)nodes_.size() - 1; i >= 0; --i) {
+        const Node &n = nodes_[i];
+        cur += n.num_wb + n.num_bn;
+        const bool last = (i == 0);
+        if ((cur * (int64_t)sizeof(float) >= bucket_bytes_ || last) && cur > 0) {
+          buckets_.push_back(Bucket{n.param_off, end - n.param_off, i});
+          end = n.param_off;
+          cur = 0;
+        }
+      }
+      while (bucket_events_.size() < buckets_.size()) {
+        unet_event_t e;
+        UNET_CALL(unet_event_create(&e));
+        bucket_events_.push_back(e);
+      }
+    }
+    return buckets_;
+  }
+  void *bucket_event(size_t i) { return bucket_events_.at(i); }
+
+  // ---- accessors -----------------------------------------------------------------
+  bool created() const { return !nodes_.empty(); }
+  const std::vector<Node> &nodes() const { return nodes_; }
+  int final_layer() const { return final_; }
+  int64_t num_parameters() const { return total_params_; }
+  float *param_ptr() const { return params_.f32(); }
+  float *grad_ptr() const { return grads_.f32(); }
+  float *loss_values_ptr() const { return loss_values_.f32(); }
+  int in_c() const { return in_c_; }
+  int in_h() const { return in_h_; }
+  int in_w() const { return in_w_; }
+  unet_stream_t stream() const { return stream_; }
+  void set_stream(unet_stream_t s) { stream_ = s; }
+  void set_verbose(bool v) { verbose_ = v; }
+  bool verbose() const { return verbose_; }
+  LossFunction loss() const { return loss_; }
+  int step_count() const { return step_count_; }
+  void set_seed(uint64_t s) { seed_ = s; }
+
+  void ensure_batch(int batch) {
+    require_created();
+    if (batch <= alloc_batch_) return;
+    const size_t b = (size_t)batch;
+    int64_t max_out = 0, max_in = 0;
+    for (Node &n : nodes_) {
+      const size_t out_bytes = sizeof(float) * b * (size_t)n.out_elems();
+      if (n.has_params()) {
+        n.z.ensure(out_bytes);
+        n.bn.ensure(out_bytes);
+      }
+      n.act.ensure(out_bytes);
+      n.grad_out.ensure(out_bytes);
+      max_out = std::max(max_out, n.out_elems());
+      int64_t in_e = n.type == CONCAT_LAYER ? n.out_elems() : n.in_elems();
+      max_in = std::max(max_in, in_e);
+    }
+    scratch_g1_.ensure(sizeof(float) * b * (size_t)max_out);
+    scratch_g2_.ensure(sizeof(float) * b * (size_t)max_out);
+    scratch_dx_.ensure(sizeof(float) * b * (size_t)max_in);
+    in_images_.ensure(sizeof(float) * b * (size_t)in_c_ * in_h_ * in_w_);
+    const Node &f = nodes_[final_];
+    in_masks_.ensure(sizeof(float) * b * (size_t)f.out_h * f.out_w);
+    loss_values_.ensure(sizeof(float) * 3 * b);
+    alloc_batch_ = batch;
+  }
+  float *input_images_ptr() const { return in_images_.f32(); }
+  float *input_masks_ptr() const { return in_masks_.f32(); }
+
+ private:
+  void require_created() const {
+    if (nodes_.empty()) throw std::runtime_error("create() must be called before using the network");
+  }
+
+  void init_node(Node &n, const LayerDesc &d) {
+    n.type = d.type;
+    n.parents = d.parents;
+    n.activation = d.activation;
+    const std::vector<int> &s = d.descriptor;
+    auto parent = [&](int i) -> const Node & { return nodes_[n.parents[i]]; };
+    switch (d.type) {
+      case CONV_LAYER: {
+        if (n.parents.size() > 1)
+          throw std::runtime_error("Convolution layers cannot have more than one parent");
+        if (s.size() != 7)
+          throw std::runtime_error(
+              "convolution layers need 7 shape values: H_in, W_in, C_in, C_out, kernel, padding, stride");
+        n.in_h = s[0]; n.in_w = s[1]; n.in_c = s[2]; n.out_c = s[3];
+        n.kernel = s[4]; n.padding = s[5]; n.stride = s[6];
+        if (n.kernel < 1 || n.kernel % 2 == 0) throw std::runtime_error("kernel must be square and odd.");
+        if (n.in_h < 1 || n.in_w < 1 || n.in_c < 1 || n.out_c < 1 || n.padding < 0 || n.stride < 1)
+          throw std::runtime_error("convolution layer: sizes must be positive");
+        n.out_h = (n.in_h + 2 * n.padding - n.kernel) / n.stride + 1;
+        n.out_w = (n.in_w + 2 * n.padding - n.kernel) / n.stride + 1;
+        if (n.out_h < 1 || n.out_w < 1) throw std::runtime_error("convolution layer: empty output");
+        n.input_shape = {n.in_c, n.in_h, n.in_w};
+        check_parent_shape(n, "convolution");
+        n.num_wb = (int64_t)n.kernel * n.kernel * n.in_c * n.out_c + n.out_c;
+        n.num_bn = 2 * (int64_t)n.out_c;
+        n.fan = (int64_t)n.kernel * n.kernel * n.in_c;
+        break;
+      }
+      case MAX_POOL_LAYER: {
+        if (n.parents.size() > 1) {
+          std::stringstream ss;
+          ss << "max pool layer must have zero or one parent. Recieved " << n.parents.size() << " parents.";
+          throw std::runtime_error(ss.str());
+        }
+        if (s.size() != 5)
+          throw std::runtime_error("max pool layers need 5 shape values: C, H, W, kernel, stride");
+        n.in_c = s[0]; n.in_h = s[1]; n.in_w = s[2]; n.kernel = s[3]; n.stride = s[4];
+        if (n.in_c < 1 || n.in_h < 1 || n.in_w < 1 || n.kernel < 1 || n.stride < 1)
+          throw std::runtime_error("max pool layer: sizes must be positive");
+        if (n.in_h % n.stride != 0 || n.in_w % n.stride != 0) {
+          std::stringstream ss;
+          ss << "max pool layer: input " << n.in_h << "x" << n.in_w << " is not divisible by stride " << n.stride;
+          throw std::runtime_error(ss.str());
+        }
+        n.out_c = n.in_c;
+        n.out_h = n.in_h / n.stride;
+        n.out_w = n.in_w / n.stride;
+        n.input_shape = {n.in_c, n.in_h, n.in_w};
+        check_parent_shape(n, "max pool");
+        break;
+      }
+      case CONCAT_LAYER: {
+        if (n.parents.size() != 2) {
+          std::stringstream ss;
+          ss << "Concat layer must have two parents. Current parent count is " << n.parents.size();
+          throw std::runtime_error(ss.str());
+        }
+        const Node &a = parent(0), &b = parent(1);
+        if (a.out_h != b.out_h || a.out_w != b.out_w) {
+          std::stringstream ss;
+          ss << "Concat layer must have equal heights and widths. Height and width of parent 1: " << a.out_h
+             << ", " << a.out_w << " Height and width of parent 2: " << b.out_h << ", " << b.out_w;
+          throw std::runtime_error(ss.str());
+        }
+        n.c1 = a.out_c; n.c2 = b.out_c;
+        n.in_c = n.c1 + n.c2; n.in_h = a.out_h; n.in_w = a.out_w;
+        n.out_c = n.in_c; n.out_h = n.in_h; n.out_w = n.in_w;
+        n.input_shape = {n.c1, n.c2, n.in_h, n.in_w};
+        break;
+      }
+      case UPSAMPLING_LAYER: {
+        if (n.parents.size() > 1) {
+          std::stringstream ss;
+          ss << "upsampling layers need 0 or 1 parents: " << n.parents.size() << " parents givent";
+          throw std::runtime_error(ss.str());
+        }
+        if (s.size() != 5)
+          throw std::runtime_error("upsampling layers need 5 shape values: H_in, W_in, C_in, C_out, scale");
+        n.in_h = s[0]; n.in_w = s[1]; n.in_c = s[2]; n.out_c = s[3]; n.kernel = s[4];
+        if (n.in_c < 1 || n.in_h < 1 || n.in_w < 1 || n.out_c < 1 || n.kernel < 1)
+          throw std::runtime_error("upsampling layer: sizes must be positive");
+        n.stride = n.kernel;
+        n.out_h = n.kernel * n.in_h;
+        n.out_w = n.kernel * n.in_w;
+        n.input_shape = {n.in_c, n.in_h, n.in_w};
+        if (!n.parents.empty()) {
+          const Node &p = parent(0);
+          if (p.out_c != n.in_c || p.out_h != n.in_h || p.out_w != n.in_w) {
+            std::stringstream ss;
+            ss << "input shape to upsampling layer does not equal output shape of parent: " << std::endl
+               << "upsampling input: " << n.in_c << ", " << n.in_h << ", " << n.in_w << ", " << std::endl
+               << "parent output: " << p.out_c << ", " << p.out_h << ", " << p.out_w << ", ";
+            throw std::runtime_error(ss.str());
+          }
+        }
+        n.num_wb = (int64_t)n.in_c * n.out_c * n.kernel * n.kernel + n.out_c;
+        n.num_bn = 2 * (int64_t)n.out_c;
+        n.fan = (int64_t)n.in_c;  // each output pixel sums C_in products
+        break;
+      }
+      case ATTENTION_LAYER:
+        throw std::runtime_error("ATTENTION_LAYER is not implemented in this build");
+      case BN_LAYER:
+        throw std::runtime_error("BN_LAYER is not implemented (batch norm is part of CONV and UPSAMPLING layers)");
+      case FC_LAYER:
+        throw std::runtime_error("FC_LAYER is not implemented");
+      default:
+        throw std::runtime_error("unknown layer type");
+    }
+    n.output_shape = {n.out_c, n.out_h, n.out_w};
+  }
+
+  void check_parent_shape(const Node &n, const char *what) {
+    if (n.parents.empty()) return;
+    const Node &p = nodes_[n.parents[0]];
+    if (p.out_c != n.in_c || p.out_h != n.in_h || p.out_w != n.in_w) {
+      std::stringstream ss;
+      ss << "input shape to " << what << " layer does not equal output shape of parent: layer input: " << n.in_c
+         << ", " << n.in_h << ", " << n.in_w << " parent output: " << p.out_c << ", " << p.out_h << ", "
+         << p.out_w;
+      throw std::runtime_error(ss.str());
+    }
+  }
+
+  const float *layer_input(const Node &n, const float *images) const {
+    return n.parents.empty() ? images : nodes_[n.parents[0]].act.f32();
+  }
+
+  // conv -> BN -> ReLU|Sigmoid ; tconv -> BN -> ReLU  (convolution_layer_functions.h:6-72,
+  // upsampling_layer_functions.h:9-70; BN always uses the layer's own gamma/beta)
+  void forward_node(Node &n, const float *images, int batch, bool inference) {
+    const int64_t out_n = (int64_t)batch * n.out_elems();
+    switch (n.type) {
+      case CONV_LAYER:
+      case UPSAMPLING_LAYER: {
+        const float *in = layer_input(n, images);
+        const float *w = params_.f32() + n.param_off;
+        const float *gb = w + n.num_wb;
+        if (n.type == CONV_LAYER)
+          UNET_CALL(unet_convolve_f32(w, in, n.z.f32(), out_n, batch, n.kernel, n.in_c, n.out_c, n.out_h, n.out_w,
+                                      n.in_h, n.in_w, n.padding, n.stride, stream_));
+        else
+          UNET_CALL(unet_upsample_f32(in, w, n.z.f32(), n.kernel, n.in_c, n.out_c, n.in_h, n.in_w, batch, stream_));
+        if (inference)
+          UNET_CALL(unet_batch_norm_inference_f32(n.z.f32(), n.bn.f32(), gb, n.running.f32(), n.out_h, n.out_w,
+                                                  n.out_c, batch, stream_));
+        else
+          UNET_CALL(unet_batch_norm_train_f32(n.z.f32(), n.bn.f32(), gb, n.batch_stats.f32(), n.running.f32(),
+                                              n.out_c, n.out_h, n.out_w, batch, stream_));
+        if (n.type == CONV_LAYER && n.activation == SIGMOID)
+          UNET_CALL(unet_sigmoid_f32(n.bn.f32(), n.act.f32(), out_n, stream_));
+        else
+          UNET_CALL(unet_relu_f32(n.bn.f32(), n.act.f32(), out_n, stream_));
+        break;
+      }
+      case MAX_POOL_LAYER:
+        UNET_CALL(unet_max_pool_f32(layer_input(n, images), n.act.f32(), batch, n.stride, n.kernel, n.in_c, n.in_h,
+                                    n.in_w, stream_));
+        break;
+      case CONCAT_LAYER:
+        UNET_CALL(unet_concat_f32(nodes_[n.parents[0]].act.f32(), nodes_[n.parents[1]].act.f32(), n.act.f32(), batch,
+                                  (int64_t)n.in_h * n.in_w, n.c1, n.c2, stream_));
+        break;
+      default:
+        throw std::runtime_error("unsupported layer type in forward");
+    }
+  }
+
+  // Where a layer's input gradient goes: straight into the parent's grad_out
+  // when it is the parent's first contribution, else into scratch followed by
+  // an add (layer.h:150-165 does a copy or cudaAddBtoA).
+  float *grad_target(Node &parent) { return parent.grad_seen ? scratch_dx_.f32() : parent.grad_out.f32(); }
+  void grad_commit(Node &parent, const float *written, int64_t count) {
+    if (parent.grad_seen)
+      UNET_CALL(unet_add_b_to_a_f32(parent.grad_out.f32(), written, count, stream_));
+    parent.grad_seen = true;
+  }
+
+  void backward_node(Node &n, const float *images, int batch) {
+    if (!n.grad_seen) return;  // not on a path to the loss
+    const int64_t out_n = (int64_t)batch * n.out_elems();
+    const int64_t in_n = (int64_t)batch * n.in_elems();
+    switch (n.type) {
+      case CONV_LAYER:
+      case UPSAMPLING_LAYER: {
+        const float *in = layer_input(n, images);
+        const float *w = params_.f32() + n.param_off;
+        float *gw = grads_.f32() + n.param_off;
+        float *g2 = scratch_g2_.f32(), *g1 = scratch_g1_.f32();
+        if (n.type == CONV_LAYER && n.activation == SIGMOID)
+          UNET_CALL(unet_sigmoid_backward_f32(n.grad_out.f32(), n.act.f32(), g2, out_n, stream_));
+        else
+          UNET_CALL(unet_relu_backward_f32(n.grad_out.f32(), n.bn.f32(), g2, out_n, stream_));
+        UNET_CALL(unet_batch_norm_backward_f32(g2, n.z.f32(), n.batch_stats.f32(), w + n.num_wb, g1, gw + n.num_wb,
+                                               n.out_c, n.out_h, n.out_w, batch, stream_));
+        float *dx = nullptr;
+        Node *p = n.parents.empty() ? nullptr : &nodes_[n.parents[0]];
+        if (p) dx = grad_target(*p);
+        if (n.type == CONV_LAYER)
+          UNET_CALL(unet_convolve_backward_f32(g1, in, w, dx, gw, batch, n.kernel, n.in_c, n.out_c, n.out_h, n.out_w,
+                                               n.in_h, n.in_w, n.padding, n.stride, stream_));
+        else
+          UNET_CALL(unet_upsample_backward_f32(g1, in, w, dx, gw, n.kernel, n.in_c, n.out_c, n.in_h, n.in_w, batch,
+                                               stream_));
+        if (p) grad_commit(*p, dx, in_n);
+        break;
+      }
+      case MAX_POOL_LAYER: {
+        if (n.parents.empty()) break;
+        Node &p = nodes_[n.parents[0]];
+        float *dx = grad_target(p);
+        UNET_CALL(unet_max_pool_backward_f32(n.grad_out.f32(), p.act.f32(), n.act.f32(), dx, batch, n.stride, n.in_c,
+                                             n.in_h, n.in_w, stream_));
+        grad_commit(p, dx, in_n);
+        break;
+      }
+      case CONCAT_LAYER: {
+        // true split: [N,C1,H,W] to parent 0, [N,C2,H,W] to parent 1
+        float *tmp = scratch_dx_.f32();
+        UNET_CALL(unet_concat_backward_f32(n.grad_out.f32(), tmp, n.in_h, n.in_w, n.c1, n.c2, batch, stream_));
+        const int64_t n1 = (int64_t)batch * n.c1 * n.in_h * n.in_w, n2 = (int64_t)batch * n.c2 * n.in_h * n.in_w;
+        Node &a = nodes_[n.parents[0]], &b = nodes_[n.parents[1]];
+        commit_copy(a, tmp, n1);
+        commit_copy(b, tmp + n1, n2);
+        break;
+      }
+      default:
+        throw std::runtime_error("unsupported layer type in backward");
+    }
+  }
+  void commit_copy(Node &parent, const float *src, int64_t count) {
+    if (parent.grad_seen)
+      UNET_CALL(unet_add_b_to_a_f32(parent.grad_out.f32(), src, count, stream_));
+    else
+      UNET_CALL(unet_memcpy_d2d(parent.grad_out.raw(), src, sizeof(float) * (size_t)count, stream_));
+    parent.grad_seen = true;
+  }
+
+  void record_finished_buckets(int layer_done) {
+    const std::vector<Bucket> &b = buckets();
+    while (next_bucket_ < b.size() && b[next_bucket_].first_layer >= layer_done) {
+      UNET_CALL(unet_event_record(bucket_events_[next_bucket_], stream_));
+      ++next_bucket_;
+    }
+  }
+
+  std::vector<Node> nodes_;
+  LossFunction loss_ = LossFunction::kDiceLoss;
+  int final_ = -1;
+  int in_c_ = 0, in_h_ = 0, in_w_ = 0;
+  int64_t total_params_ = 0;
+  DeviceBuffer params_, grads_, adam_;
+  DeviceBuffer scratch_g1_, scratch_g2_, scratch_dx_;
+  DeviceBuffer in_images_, in_masks_, loss_values_;
+  int alloc_batch_ = 0;
+  int step_count_ = 0;
+  uint64_t seed_ = 0;
+  bool params_dirty_ = true;
+  bool verbose_ = true;
+  unet_stream_t stream_ = nullptr;
+  int64_t bucket_bytes_ = 8 << 20;
+  std::vector<Bucket> buckets_;
+  std::vector<void *> bucket_events_;
+  size_t next_bucket_ = 0;
+};
+
+}  // namespace unet
