@@ -1,0 +1,250 @@
+#!/usr/bin/env python3
+"""Throughput benchmark of the U-Net training hot path.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A step = one forward + backward + Adam update over one batch of synthetic
+images on every rank (one process per GPU; for N > 1 launch with
+`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`).
+Inputs are resident in HBM before the timed region starts.  Rank 0 prints ONE
+JSON line: whole-job images/s, the roofline position of the dominant kernel
+family (timed live with HIP events on the launch stream) and, at N = 1, a CPU
+baseline of a bounded sample of the same workload.
+
+Workload (config.workload): BASELINE.json configs[2] -- U-Net fwd+bwd training
+step with BatchNorm, batch 16 x 3 x 256 x 256 per GPU -- on the classic
+4-down/4-up double-conv base-64 graph of configs[1] ("unet4_base64") or the
+reference's own main.py graph ("mainpy", 3 down / 3 up, single conv).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+os.environ.setdefault("UNET_QUIET", "1")
+
+# Dense peaks used for roofline fractions (MI355X, gfx950):
+PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}   # bf16 MFMA dense; fp32 vector/matrix
+PEAK_HBM_GBS = 8000.0
+
+
+def conv_flops(graph, batch):
+    """Algorithmic FLOPs of one training step: 2*N*Co*Ho*Wo*Ci*k*k per conv pass,
+    three passes (forward, data gradient, weight gradient); the first layer has
+    no data gradient."""
+    fwd = 0.0
+    total = 0.0
+    for kind, s, parents, _ in graph:
+        if kind == "conv":
+            f = 2.0 * s[0] * s[1] * s[3] * s[2] * s[4] * s[4]
+        elif kind == "up":
+            f = 2.0 * (s[0] * s[4]) * (s[1] * s[4]) * s[3] * s[2]
+        else:
+            continue
+        fwd += f
+        total += f * (3 if parents else 2)
+    return fwd * batch, total * batch
+
+
+def cpu_baseline_port(seconds_budget=30.0):
+    """Times the CPU oracle (single thread, plain C) on a bounded sample of the
+    workload: one image through the 64->64 3x3 convolution at 256x256 (forward +
+    backward), i.e. one of the two stage-1 convolutions; scales by FLOPs to an
+    images/s figure for the whole step."""
+    import oracle
+    rng = np.random.default_rng(0)
+    hw = 256
+    x = rng.standard_normal((1, 64, hw, hw)).astype(np.float32)
+    w = (rng.standard_normal(64 * 64 * 9 + 64) * 0.05).astype(np.float32)
+    t0 = time.perf_counter()
+    y = oracle.convolve(x, w, 64, 3, 1, 1)
+    dy = rng.standard_normal(y.shape).astype(np.float32)
+    oracle.convolve_backward(x, dy, w, 3, 1, 1)
+    dt = time.perf_counter() - t0
+    return dt, 3 * 2.0 * hw * hw * 64 * 64 * 9
+
+
+def cpu_baseline_torch(graph, batch=1, steps=1):
+    """PyTorch-CPU (the oracle of test/torch_compare.py): fwd+bwd of the same
+    graph in fp32 with all host threads."""
+    import torch
+    import torch_ref
+    cores = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "0") or 0) or (os.cpu_count() or 1))
+    torch.set_num_threads(cores)
+    rng = np.random.default_rng(0)
+    n = torch_ref.param_count(graph)
+    flat = rng.standard_normal(n) * 0.05
+    params = torch_ref.split_params(graph, flat)
+    for p in params:
+        if p is not None:
+            for k in p:
+                p[k] = p[k].detach().float().requires_grad_(True)
+    s0 = graph[0][1]
+    x = torch.randn(batch, s0[2], s0[0], s0[1])
+    m = (torch.rand(batch, s0[0], s0[1]) < 0.03).float()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        acts = torch_ref.forward(graph, params, x)
+        torch_ref.dice_loss(acts[-1], m).backward()
+    return (time.perf_counter() - t0) / steps, cores
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=16, help="images per GPU per step")
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--graph", default=os.environ.get("UNET_BENCH_GRAPH", "unet4_base64"),
+                    choices=["unet4_base64", "mainpy"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-prof", action="store_true", help="skip the per-kernel event timing")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import neural_net as nn
+    import torch_ref
+    from unet_amd import capi, dp
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    capi.unet_set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    H = W = args.size
+    graph = (torch_ref.unet_graph(H, W, 3, 64, 4, True) if args.graph == "unet4_base64"
+             else torch_ref.main_py_graph(H, W, 3, 64))
+    net = nn.NeuralNet()
+    net.set_seed(1)
+    net.create(torch_ref.to_layer_descs(nn, graph), nn.LossFunction.DICE_LOSS)
+    net.reserve(args.batch)
+    dtype = net.compute_dtype() if hasattr(net, "compute_dtype") else "f32"
+
+    # synthetic data, generated once, resident on the device
+    rng = np.random.default_rng(1234 + rank)
+    images = torch.from_numpy(rng.standard_normal((args.batch, 3, H, W)).astype(np.float32)).to(device)
+    masks = torch.from_numpy((rng.random((args.batch, H, W)) < 0.03).astype(np.float32)).to(device)
+    trainer = dp.DataParallel(net, device)
+    trainer.broadcast_parameters()
+    lr = 1e-3
+
+    def sync():
+        net.synchronize()
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(device)
+
+    for _ in range(args.warmup):
+        trainer.train_step(images.data_ptr(), masks.data_ptr(), args.batch, lr)
+    sync()
+    if not args.no_prof:
+        capi.unet_prof_enable(1)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        trainer.train_step(images.data_ptr(), masks.data_ptr(), args.batch, lr)
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # per-kernel-family timing from the HIP events recorded in the timed region
+    families = {}
+    if not args.no_prof:
+        kinds = ctypes.c_int()
+        capi.unet_prof_kinds(ctypes.byref(kinds))
+        for k in range(kinds.value):
+            n, ms, fl, by = ctypes.c_int64(), ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+            capi.unet_prof_get(k, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(by))
+            if n.value:
+                families[capi.lib().unet_prof_name(k).decode()] = dict(
+                    launches=n.value, ms=ms.value, flops=fl.value, bytes=by.value)
+        capi.unet_prof_enable(0)
+
+    loss = None
+    if rank == 0:
+        lv = torch.zeros(3 * args.batch, device=device)
+        capi.unet_memcpy_d2d(lv.data_ptr(), net.loss_values_ptr(), 12 * args.batch, None)
+        torch.cuda.synchronize(device)
+        lv = lv.cpu().numpy().reshape(-1, 3)
+        loss = float(1.0 - np.mean(2 * lv[:, 0] / (lv[:, 1] + lv[:, 2] + 1e-5)))
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    ms_per_step = elapsed / args.steps * 1e3
+    value = args.batch * world * args.steps / elapsed
+    fwd_flops, step_flops = conv_flops(graph, args.batch)
+    out = {
+        "metric": "U-Net train images/s (fwd+bwd, 256x256, bf16)",
+        "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+        "config": {"workload": f"{args.graph} train step (fwd+bwd+Adam, BatchNorm, Dice loss), "
+                               f"batch {args.batch}x3x{H}x{W} per GPU",
+                   "global_batch": args.batch * world, "parallelism": f"dp{world}",
+                   "parameters": int(net.num_parameters()), "conv_tflop_per_step": round(step_flops / 1e12, 3)},
+        "step_tflops": round(step_flops * world / elapsed * args.steps / 1e12, 2),
+        "final_loss": loss,
+    }
+    if families:
+        # dominant family = the one with the largest share of device time
+        name, f = max(families.items(), key=lambda kv: kv[1]["ms"])
+        if f["flops"] > 0 and ("conv" in name or "tconv" in name):
+            achieved = f["flops"] / (f["ms"] * 1e-3) / 1e12
+            peak = PEAK_TFLOPS["bf16" if "bf16" in name else "f32"]
+            out["roofline"] = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": peak,
+                               "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
+                               "avg_launch_us": round(f["ms"] * 1e3 / f["launches"], 2), "launches": f["launches"]}
+        else:
+            achieved = f["bytes"] / (f["ms"] * 1e-3) / 1e9
+            out["roofline"] = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 1), "peak": PEAK_HBM_GBS,
+                               "unit": "GB/s", "frac": round(achieved / PEAK_HBM_GBS, 4), "traffic": None,
+                               "avg_launch_us": round(f["ms"] * 1e3 / f["launches"], 2), "launches": f["launches"]}
+        out["kernel_families"] = {
+            k: {"launches": v["launches"], "ms_per_step": round(v["ms"] / args.steps, 3),
+                "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["flops"] else None,
+                "gbs": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["bytes"] else None}
+            for k, v in sorted(families.items(), key=lambda kv: -kv[1]["ms"])}
+    if world == 1 and not args.no_cpu_baseline:
+        dt, sample_flops = cpu_baseline_port()
+        img_flops = step_flops / args.batch
+        out["cpu_baseline"] = {
+            "value": round(1.0 / (dt * img_flops / sample_flops), 5), "unit": "images/s", "cores": 1,
+            "kind": "port",
+            "sample": f"C oracle, 1 image through one 64->64 3x3 conv at 256x256 fwd+bwd ({dt:.1f} s, "
+                      f"{sample_flops / 1e9:.1f} GFLOP of {img_flops / 1e9:.0f} GFLOP/image), scaled by FLOPs"}
+        try:
+            tdt, cores = cpu_baseline_torch(graph, 1, 1)
+            out["cpu_torch_oracle"] = {"value": round(1.0 / tdt, 4), "unit": "images/s", "cores": cores,
+                                       "sample": f"PyTorch-CPU fp32 fwd+bwd of the same graph, batch 1, {tdt:.1f} s"}
+        except Exception as e:  # the torch figure is a side note; never fail the bench on it
+            out["cpu_torch_oracle"] = {"error": str(e)[:200]}
+    print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -67,6 +67,18 @@ int unet_event_synchronize(unet_event_t event);
 int unet_stream_wait_event(unet_stream_t stream, unet_event_t event);
 int unet_event_elapsed_ms(float *ms, unet_event_t start, unet_event_t stop);
 
+/* Per-kernel timing with HIP events recorded on the launch stream (no
+ * counterpart in the reference).  unet_prof_enable(1) clears the records and
+ * starts recording around the launches of the convolution / batch-norm /
+ * pooling kernel families; unet_prof_get() synchronises on the recorded events
+ * and returns, for family `kind` (0 <= kind < unet_prof_kinds), the number of
+ * launches, their summed duration, and the algorithmic FLOPs and bytes the
+ * launchers attributed to them. */
+int unet_prof_enable(int on);
+int unet_prof_kinds(int *count);
+const char *unet_prof_name(int kind);
+int unet_prof_get(int kind, int64_t *launches, double *total_ms, double *total_flops, double *total_bytes);
+
 /* ---- memory ------------------------------------------------------------ */
 
 /* Replaces cudaGetPointer<T>(n, ZERO) (cuda_ops.cu:32-57): allocate `bytes`

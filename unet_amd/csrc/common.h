@@ -41,6 +41,37 @@ void unet_workspace_release_all();
 
 static inline hipStream_t as_stream(unet_stream_t s) { return (hipStream_t)s; }
 
+// ---- per-kernel timing (unet_prof_* in the C ABI) ---------------------------
+// When enabled, a ProfScope around a launch records two HIP events on the
+// launch stream; unet_prof_get() later sums the elapsed times per kind.
+enum UnetProfKind {
+  PROF_CONV_FWD_F32 = 0,
+  PROF_CONV_DGRAD_F32,
+  PROF_CONV_WGRAD_F32,
+  PROF_TCONV_F32,
+  PROF_BN_F32,
+  PROF_CONV_FWD_BF16,
+  PROF_CONV_DGRAD_BF16,
+  PROF_CONV_WGRAD_BF16,
+  PROF_TCONV_BF16,
+  PROF_BN_RELU_BF16,
+  PROF_POOL_BF16,
+  PROF_KINDS
+};
+bool unet_prof_on();
+void unet_prof_mark(int kind, double flops, double bytes, hipStream_t s, bool begin);
+struct ProfScope {
+  int kind;
+  hipStream_t s;
+  bool on;
+  ProfScope(int k, double flops, double bytes, hipStream_t st) : kind(k), s(st), on(unet_prof_on()) {
+    if (on) unet_prof_mark(kind, flops, bytes, s, true);
+  }
+  ~ProfScope() {
+    if (on) unet_prof_mark(kind, 0, 0, s, false);
+  }
+};
+
 static inline unsigned cdiv_u(i64 a, i64 b) { return (unsigned)((a + b - 1) / b); }
 
 // Grid for grid-stride elementwise kernels: enough blocks to fill 256 CUs

@@ -406,6 +406,8 @@ int unet_convolve_f32(const float *weights, const float *inputs, float *activati
                           stride, lds);
   const int tilesH = (Ho + TILE - 1) / TILE, tilesW = (Wo + TILE - 1) / TILE;
   dim3 grid((unsigned)(tilesH * tilesW), (unsigned)((Co + F_COB - 1) / F_COB), (unsigned)N);
+  const double flops = 2.0 * N * Co * Ho * Wo * (double)Ci * k * k;
+  ProfScope prof(PROF_CONV_FWD_F32, flops, 4.0 * ((double)N * Ci * Hi * Wi + (double)N * Co * Ho * Wo), as_stream(s));
   if (k == 3)
     hipLaunchKernelGGL(conv_fwd_f32_kernel<3>, grid, dim3(256), lds, as_stream(s), weights, inputs, activations,
                        Ci, Co, Ho, Wo, Hi, Wi, pad, stride, k, tilesW);
@@ -440,6 +442,8 @@ int unet_convolve_backward_f32(const float *grad_activations, const float *input
       return unet_set_error(UNET_ERR_UNSUPPORTED, "unet_convolve_backward_f32: needs %zu B of LDS", lds);
     const int tilesH = (Hi + TILE - 1) / TILE, tilesW = (Wi + TILE - 1) / TILE;
     dim3 grid((unsigned)(tilesH * tilesW), (unsigned)((Ci + D_CIB - 1) / D_CIB), (unsigned)N);
+    ProfScope prof(PROF_CONV_DGRAD_F32, 2.0 * N * Co * Ho * Wo * (double)Ci * k * k,
+                   4.0 * ((double)N * Ci * Hi * Wi + (double)N * Co * Ho * Wo), as_stream(s));
     hipLaunchKernelGGL(conv_bwd_data_f32_kernel, grid, dim3(256), lds, as_stream(s), weights, grad_activations,
                        grad_inputs, Ci, Co, Ho, Wo, Hi, Wi, pad, stride, k, tilesW, PH);
     UNET_LAUNCH_CHECK("conv_bwd_data_f32_kernel");
@@ -456,6 +460,8 @@ int unet_convolve_backward_f32(const float *grad_activations, const float *input
   int rc = unet_workspace(&ws, sizeof(float) * (size_t)splits * (size_t)(nW + Co));
   if (rc) return rc;
   dim3 grid((unsigned)splits, (unsigned)cogroups, (unsigned)Ci);
+  ProfScope prof(PROF_CONV_WGRAD_F32, 2.0 * N * Co * Ho * Wo * (double)Ci * k * k,
+                 4.0 * ((double)N * Ci * Hi * Wi + (double)N * Co * Ho * Wo), as_stream(s));
 #define LAUNCH_BW(KK_, COB_)                                                                               \
   hipLaunchKernelGGL((conv_bwd_weight_f32_kernel<KK_, COB_>), grid, dim3(256), 0, as_stream(s), grad_activations, \
                      inputs, (float *)ws, N, Ci, Co, Ho, Wo, Hi, Wi, pad, stride, rps, nW)

@@ -3,6 +3,7 @@
 #include <string.h>
 
 #include <mutex>
+#include <vector>
 
 #include "common.h"
 
@@ -62,7 +63,84 @@ void unet_workspace_release_all() {
   (void)hipSetDevice(cur);
 }
 
+// ---- profiling ---------------------------------------------------------------
+namespace {
+struct ProfRec {
+  int kind;
+  double flops, bytes;
+  hipEvent_t a, b;
+};
+std::mutex g_prof_mu;
+bool g_prof_enabled = false;
+std::vector<ProfRec> g_prof_recs;
+std::vector<hipEvent_t> g_prof_pool;
+const char *kProfNames[PROF_KINDS] = {
+    "conv_fwd_f32",   "conv_dgrad_f32",  "conv_wgrad_f32",  "tconv_f32",  "batch_norm_f32", "conv_fwd_bf16",
+    "conv_dgrad_bf16", "conv_wgrad_bf16", "tconv_bf16", "bn_relu_bf16", "pool_bf16"};
+hipEvent_t prof_event() {
+  if (!g_prof_pool.empty()) {
+    hipEvent_t e = g_prof_pool.back();
+    g_prof_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e = nullptr;
+  (void)hipEventCreate(&e);
+  return e;
+}
+}  // namespace
+
+bool unet_prof_on() { return g_prof_enabled; }
+void unet_prof_mark(int kind, double flops, double bytes, hipStream_t s, bool begin) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  if (begin) {
+    ProfRec r{kind, flops, bytes, prof_event(), prof_event()};
+    (void)hipEventRecord(r.a, s);
+    g_prof_recs.push_back(r);
+  } else {
+    for (size_t i = g_prof_recs.size(); i-- > 0;)
+      if (g_prof_recs[i].kind == kind) {
+        (void)hipEventRecord(g_prof_recs[i].b, s);
+        break;
+      }
+  }
+}
+
 extern "C" {
+
+int unet_prof_enable(int on) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  for (ProfRec &r : g_prof_recs) {
+    g_prof_pool.push_back(r.a);
+    g_prof_pool.push_back(r.b);
+  }
+  g_prof_recs.clear();
+  g_prof_enabled = on != 0;
+  return UNET_OK;
+}
+int unet_prof_kinds(int *count) {
+  UNET_REQUIRE(count, "count is NULL");
+  *count = PROF_KINDS;
+  return UNET_OK;
+}
+const char *unet_prof_name(int kind) { return (kind >= 0 && kind < PROF_KINDS) ? kProfNames[kind] : ""; }
+int unet_prof_get(int kind, int64_t *launches, double *total_ms, double *total_flops, double *total_bytes) {
+  UNET_REQUIRE(kind >= 0 && kind < PROF_KINDS && launches && total_ms && total_flops && total_bytes,
+               "unet_prof_get: bad argument");
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  *launches = 0;
+  *total_ms = *total_flops = *total_bytes = 0;
+  for (const ProfRec &r : g_prof_recs) {
+    if (r.kind != kind) continue;
+    float ms = 0.f;
+    UNET_HIP_TRY(hipEventSynchronize(r.b));
+    UNET_HIP_TRY(hipEventElapsedTime(&ms, r.a, r.b));
+    *launches += 1;
+    *total_ms += ms;
+    *total_flops += r.flops;
+    *total_bytes += r.bytes;
+  }
+  return UNET_OK;
+}
 
 const char *unet_last_error(void) { return g_err; }
 int unet_version(void) { return 100; }
