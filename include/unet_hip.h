@@ -256,6 +256,56 @@ int unet_threshold_f32(float *x, float threshold, int64_t num_elements, unet_str
 /* x *= alpha (gradient averaging across data-parallel ranks). */
 int unet_scale_f32(float *x, float alpha, int64_t num_elements, unet_stream_t stream);
 
+/* ==== bf16 / NHWC fast path =================================================
+ * The training hot path of the network engine.  Activations are NHWC bf16
+ * (uint16_t storage) with a pixel stride `ld` in elements, so a tensor may be
+ * a channel slice of a wider buffer (the skip-connection concat is then free).
+ * Channel counts are padded to multiples of 32 ("CiP", "CoP"); pad channels
+ * hold zeros.  Accumulation is fp32 on the matrix cores.  These entry points
+ * fuse what the reference runs as separate kernels (cudaConvolve +
+ * cudaBatchNormTrain's statistics pass, cudaBatchNormTrain's normalise +
+ * cudaRelu, cudaReluBackward + cudaBatchNormBackward, ...); their fp32
+ * one-to-one counterparts are above. */
+
+/* w_ref [Ci][Co][K][K] fp32 (reference layout) -> packed bf16, zero padded:
+ *   w_fwd [K*K][CoP][CiP]            (forward operand)
+ *   w_bwd [K*K][CiP][CoP], taps flipped for K=3 (data-gradient operand)
+ * K = 3 (convolution) or 2 (the four phases of the 2x2 transposed
+ * convolution).  Either output may be NULL. */
+int unet_pack_weights_bf16(const float *w_ref, uint16_t *w_fwd, uint16_t *w_bwd, int Ci, int Co, int CiP,
+                           int CoP, int K, unet_stream_t stream);
+/* NCHW fp32 -> NHWC bf16 (pixel stride ld); channels [C, Cpad) are zeroed. */
+int unet_nchw_f32_to_nhwc_bf16(const float *in, uint16_t *out, int N, int C, int H, int W, int ld, int Cpad,
+                               unet_stream_t stream);
+int unet_nhwc_bf16_to_nchw_f32(const uint16_t *in, float *out, int N, int C, int H, int W, int ld,
+                               unet_stream_t stream);
+
+/* 3x3, padding 1, stride 1 convolution as an implicit GEMM on bf16 MFMA
+ * (cudaConvolve, and with w_bwd / bias = NULL the data-gradient half of
+ * cudaConvolveBackward).  out = conv(in) + bias, rounded to bf16; when
+ * accumulate != 0 the result is added to what `out` holds (gradient fan-in).
+ * stat_partials (optional) receives [N][tiles][CoP][2] per-tile (sum, sum of
+ * squares) of the rounded outputs, tiles = unet_conv3x3_stat_tiles(H, W). */
+int unet_conv3x3_bf16(const uint16_t *in, int in_ld, const uint16_t *w_packed, const float *bias, int co_valid,
+                      uint16_t *out, int out_ld, float *stat_partials, int N, int H, int W, int CiP, int CoP,
+                      int accumulate, unet_stream_t stream);
+int unet_conv3x3_stat_tiles(int H, int W);
+/* Weight-gradient half of cudaConvolveBackward: grad_w [Ci][Co][3][3] fp32
+ * (overwritten) = sum over pixels of dz x shifted x.  Deterministic. */
+int unet_conv3x3_wgrad_bf16(const uint16_t *dz, int dz_ld, const uint16_t *x, int x_ld, float *grad_w, int N, int H,
+                            int W, int CiP, int CoP, int Ci, int Co, unet_stream_t stream);
+
+/* 2x2 stride-2 transposed convolution (cudaUpsample / cudaUpsampleBackward):
+ * out[n,2h+i,2w+j,co] = bias[co] + sum_ci in[n,h,w,ci] * W[ci,co,i,j].
+ * stat_partials: [4][N][tiles][CoP][2] with tiles of the INPUT grid. */
+int unet_tconv2x2_bf16(const uint16_t *in, int in_ld, const uint16_t *w_packed, const float *bias, int co_valid,
+                       uint16_t *out, int out_ld, float *stat_partials, int N, int H_in, int W_in, int CiP, int CoP,
+                       unet_stream_t stream);
+int unet_tconv2x2_dgrad_bf16(const uint16_t *dy, int dy_ld, const uint16_t *w_packed_bwd, uint16_t *dx, int dx_ld,
+                             int N, int H_in, int W_in, int CiP, int CoP, int accumulate, unet_stream_t stream);
+int unet_tconv2x2_wgrad_bf16(const uint16_t *dy, int dy_ld, const uint16_t *x, int x_ld, float *grad_w, int N,
+                             int H_in, int W_in, int CiP, int CoP, int Ci, int Co, unet_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

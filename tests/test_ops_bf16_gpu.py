@@ -1,0 +1,181 @@
+"""GPU parity tests of the bf16 / NHWC fast path (MFMA implicit-GEMM
+convolution, transposed convolution, weight gradients) against the CPU oracle.
+
+Inputs are rounded to bf16 first, so both sides see identical operands; the
+HIP side accumulates in fp32 and rounds outputs to bf16.  Bar: bf16 relative
+<= 2e-2 (util.assert_close_bf16); fp32 outputs (weight gradients, statistics)
+are held to 1e-3 of the tensor's magnitude.
+"""
+import numpy as np
+import pytest
+import torch
+
+from util import assert_close, assert_close_bf16
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def G():
+    import gpu_util
+    return gpu_util
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from unet_amd import capi as c
+    c.lib()
+    return c
+
+
+def bf16_round(a):
+    return torch.from_numpy(np.ascontiguousarray(a, np.float32)).bfloat16().float().numpy()
+
+
+def pad32(c):
+    return (c + 31) // 32 * 32
+
+
+def to_nhwc(G, capi, x, ld=None, cpad=None):
+    n, c, h, w = x.shape
+    cpad = cpad or pad32(c)
+    ld = ld or cpad
+    xd = G.dev(x)
+    out = torch.zeros((n, h, w, ld), dtype=torch.bfloat16, device=G.DEV)
+    capi.unet_nchw_f32_to_nhwc_bf16(G.p(xd), G.p(out), n, c, h, w, ld, cpad, None)
+    return out
+
+
+def from_nhwc(G, capi, t, c):
+    n, h, w, ld = t.shape
+    out = G.empty((n, c, h, w))
+    capi.unet_nhwc_bf16_to_nchw_f32(G.p(t), G.p(out), n, c, h, w, ld, None)
+    return G.host(out)
+
+
+def pack(G, capi, w_flat, ci, co, k):
+    cip, cop = pad32(ci), pad32(co)
+    wd = G.dev(w_flat)
+    fwd = torch.zeros(k * k * cop * cip, dtype=torch.bfloat16, device=G.DEV)
+    bwd = torch.zeros(k * k * cop * cip, dtype=torch.bfloat16, device=G.DEV)
+    capi.unet_pack_weights_bf16(G.p(wd), G.p(fwd), G.p(bwd), ci, co, cip, cop, k, None)
+    return fwd, bwd
+
+
+def test_layout_round_trip(G, capi):
+    rng = np.random.default_rng(0)
+    x = bf16_round(rng.standard_normal((2, 5, 7, 9)))
+    t = to_nhwc(G, capi, x, ld=40, cpad=32)
+    th = t.float().cpu().numpy()
+    np.testing.assert_array_equal(th[..., :5], x.transpose(0, 2, 3, 1))
+    assert np.all(th[..., 5:32] == 0)
+    np.testing.assert_array_equal(from_nhwc(G, capi, t, 5), x)
+
+
+CONV_CASES = [
+    # n, ci, co, h, w
+    (2, 32, 64, 16, 16),
+    (1, 64, 32, 20, 36),     # ragged tiles, BN=32 path
+    (2, 96, 128, 8, 8),      # small image, 3 K chunks, 2 channel tiles
+    (1, 3, 64, 33, 17),      # first-layer-like (C_in padded 3 -> 32)
+    (2, 64, 1, 16, 24),      # last-layer-like (C_out padded 1 -> 32)
+    (1, 128, 64, 48, 48),
+]
+
+
+@pytest.mark.parametrize("cfg", CONV_CASES)
+def test_conv3x3_forward_dgrad_wgrad(G, capi, oracle, cfg):
+    n, ci, co, h, w = cfg
+    cip, cop = pad32(ci), pad32(co)
+    rng = np.random.default_rng(ci * 7 + co)
+    x = bf16_round(rng.standard_normal((n, ci, h, w)))
+    wt = bf16_round(rng.standard_normal(ci * co * 9) * (1.0 / np.sqrt(9 * ci)))
+    bias = (rng.standard_normal(co) * 0.5).astype(np.float32)
+    w_and_b = np.concatenate([wt, bias]).astype(np.float32)
+    dy = bf16_round(rng.standard_normal((n, co, h, w)))
+
+    xt = to_nhwc(G, capi, x)
+    fwd, bwd = pack(G, capi, wt, ci, co, 3)
+    bd = G.dev(bias)
+    tiles = capi.lib().unet_conv3x3_stat_tiles(h, w)
+    out = torch.full((n, h, w, cop), float("nan"), dtype=torch.bfloat16, device=G.DEV)
+    stats = G.empty((n, tiles, cop, 2))
+    capi.unet_conv3x3_bf16(G.p(xt), cip, G.p(fwd), G.p(bd), co, G.p(out), cop, G.p(stats), n, h, w, cip, cop, 0, None)
+    y = from_nhwc(G, capi, out, co)
+    y_ref = oracle.convolve(x, w_and_b, co, 3, 1, 1)
+    assert_close_bf16(y, y_ref, what=f"conv3x3 bf16 forward {cfg}")
+    outh = out.float().cpu().numpy()
+    assert np.all(outh[..., co:] == 0), "padded output channels must be zero"
+    # statistics are sums of the ROUNDED outputs
+    st = G.host(stats).sum(axis=(0, 1))
+    assert_close(st[:co, 0], y.sum(axis=(0, 2, 3)), rtol=1e-4, atol_scale=1e-5, what="conv stats sum")
+    assert_close(st[:co, 1], (y.astype(np.float64) ** 2).sum(axis=(0, 2, 3)), rtol=1e-4, atol_scale=1e-5,
+                 what="conv stats sum of squares")
+
+    # data gradient = forward kernel over dy with the flipped / transposed weights
+    dyt = to_nhwc(G, capi, dy)
+    dx = torch.full((n, h, w, cip), float("nan"), dtype=torch.bfloat16, device=G.DEV)
+    capi.unet_conv3x3_bf16(G.p(dyt), cop, G.p(bwd), None, 0, G.p(dx), cip, None, n, h, w, cop, cip, 0, None)
+    dx_ref, dw_ref = oracle.convolve_backward(x, dy, w_and_b, 3, 1, 1)
+    assert_close_bf16(from_nhwc(G, capi, dx, ci), dx_ref, what=f"conv3x3 bf16 dgrad {cfg}")
+    # accumulate mode adds to what the buffer holds
+    capi.unet_conv3x3_bf16(G.p(dyt), cop, G.p(bwd), None, 0, G.p(dx), cip, None, n, h, w, cop, cip, 1, None)
+    assert_close_bf16(from_nhwc(G, capi, dx, ci), 2 * dx_ref, what=f"conv3x3 bf16 dgrad accumulate {cfg}")
+
+    # weight gradient, fp32 in the reference layout
+    gw = G.empty((ci * co * 9,))
+    capi.unet_conv3x3_wgrad_bf16(G.p(dyt), cop, G.p(xt), cip, G.p(gw), n, h, w, cip, cop, ci, co, None)
+    ref = dw_ref[:ci * co * 9]
+    got = G.host(gw)
+    assert np.abs(got - ref).max() <= 1e-3 * np.abs(ref).max(), (np.abs(got - ref).max(), np.abs(ref).max())
+
+
+def test_conv3x3_reads_channel_slices(G, capi, oracle):
+    """Input and output tensors that are channel slices of wider buffers
+    (pixel stride > channel count): the zero-copy concat layout."""
+    n, ci, co, h, w = 1, 32, 32, 16, 16
+    rng = np.random.default_rng(3)
+    x = bf16_round(rng.standard_normal((n, ci, h, w)))
+    wt = bf16_round(rng.standard_normal(ci * co * 9) * 0.1)
+    big_in = torch.full((n, h, w, 96), 7.0, dtype=torch.bfloat16, device=G.DEV)
+    big_in[..., 64:96] = torch.from_numpy(x.transpose(0, 2, 3, 1)).to(G.DEV).bfloat16()
+    big_out = torch.full((n, h, w, 64), 5.0, dtype=torch.bfloat16, device=G.DEV)
+    fwd, _ = pack(G, capi, wt, ci, co, 3)
+    capi.unet_conv3x3_bf16(big_in.data_ptr() + 64 * 2, 96, G.p(fwd), None, 0, big_out.data_ptr() + 32 * 2, 64, None,
+                           n, h, w, 32, 32, 0, None)
+    res = big_out.float().cpu().numpy()
+    assert np.all(res[..., :32] == 5.0), "channels outside the slice must be untouched"
+    y_ref = oracle.convolve(x, np.concatenate([wt, np.zeros(co, np.float32)]), co, 3, 1, 1)
+    assert_close_bf16(res[..., 32:].transpose(0, 3, 1, 2), y_ref, what="conv into a channel slice")
+
+
+@pytest.mark.parametrize("cfg", [(2, 64, 32, 8, 8), (1, 32, 64, 20, 12), (1, 128, 64, 16, 16)])
+def test_tconv2x2(G, capi, oracle, cfg):
+    n, ci, co, h, w = cfg
+    cip, cop = pad32(ci), pad32(co)
+    rng = np.random.default_rng(ci + co)
+    x = bf16_round(rng.standard_normal((n, ci, h, w)))
+    wt = bf16_round(rng.standard_normal(ci * co * 4) * (1.0 / np.sqrt(ci)))
+    bias = (rng.standard_normal(co) * 0.5).astype(np.float32)
+    w_and_b = np.concatenate([wt, bias]).astype(np.float32)
+    dy = bf16_round(rng.standard_normal((n, co, 2 * h, 2 * w)))
+    xt, dyt = to_nhwc(G, capi, x), to_nhwc(G, capi, dy)
+    fwd, bwd = pack(G, capi, wt, ci, co, 2)
+    bd = G.dev(bias)
+    tiles = capi.lib().unet_conv3x3_stat_tiles(h, w)
+    out = torch.full((n, 2 * h, 2 * w, cop), float("nan"), dtype=torch.bfloat16, device=G.DEV)
+    stats = G.empty((4, n, tiles, cop, 2))
+    capi.unet_tconv2x2_bf16(G.p(xt), cip, G.p(fwd), G.p(bd), co, G.p(out), cop, G.p(stats), n, h, w, cip, cop, None)
+    y = from_nhwc(G, capi, out, co)
+    assert_close_bf16(y, oracle.upsample(x, w_and_b, co, 2), what=f"tconv forward {cfg}")
+    st = G.host(stats).sum(axis=(0, 1, 2))
+    assert_close(st[:co, 0], y.sum(axis=(0, 2, 3)), rtol=1e-4, atol_scale=1e-5, what="tconv stats sum")
+    dx_ref, dw_ref = oracle.upsample_backward(x, w_and_b, dy, 2)
+    dx = torch.full((n, h, w, cip), float("nan"), dtype=torch.bfloat16, device=G.DEV)
+    capi.unet_tconv2x2_dgrad_bf16(G.p(dyt), cop, G.p(bwd), G.p(dx), cip, n, h, w, cip, cop, 0, None)
+    assert_close_bf16(from_nhwc(G, capi, dx, ci), dx_ref, what=f"tconv dgrad {cfg}")
+    gw = G.empty((ci * co * 4,))
+    capi.unet_tconv2x2_wgrad_bf16(G.p(dyt), cop, G.p(xt), cip, G.p(gw), n, h, w, cip, cop, ci, co, None)
+    ref = dw_ref[:ci * co * 4]
+    got = G.host(gw)
+    assert np.abs(got - ref).max() <= 1e-3 * np.abs(ref).max(), (np.abs(got - ref).max(), np.abs(ref).max())

@@ -1,0 +1,706 @@
+// bf16 implicit-GEMM convolution on the gfx950 matrix cores.
+//
+// Activations are NHWC bf16 (channels innermost, pixel stride `ld` elements so
+// that a tensor can be a channel slice of a wider buffer -- that is how the
+// skip-connection concat costs no copy).  Weights are packed per filter tap as
+// [tap][C_out][C_in] bf16 (C_in innermost) by unet_pack_weights_bf16.
+//
+// conv_mfma_kernel<TAPS,BN>:   D[co][pixel] = sum_tap sum_ci W[tap][co][ci] * X[pixel + off(tap)][ci]
+//   - one workgroup (4 waves) = one 16x16 pixel tile of one image x BN output
+//     channels; wave w owns pixel rows 4w..4w+3 (two 32-pixel MFMA column
+//     blocks) and all BN channels (BN/32 MFMA row blocks);
+//   - v_mfma_f32_32x32x16_bf16 with the WEIGHTS as the A operand (rows =
+//     channels) and the PIXELS as the B operand (columns = pixels), so each lane
+//     ends up with 4 consecutive channels of one pixel per accumulator quad:
+//     8-byte packed bf16 writes into the LDS staging tile, then whole 16-byte
+//     row pieces go to HBM;
+//   - K loop over C_in in chunks of 32 channels: the (16+2)^2 input halo patch
+//     and the 9 x BN x 32 weight slice are staged in LDS (rows padded to 80
+//     bytes: 16-byte pieces of consecutive rows fall in distinct bank groups),
+//     the next chunk's global loads are issued before the MFMAs of the current
+//     one and written to LDS after them (register prefetch);
+//   - fp32 accumulation; epilogue adds the bias, rounds to bf16 and (optionally)
+//     emits per-tile per-channel sum / sum-of-squares for the batch norm that
+//     follows, so the statistics pass needs no second read of the tensor.
+// TAPS = 9: 3x3, pad 1, stride 1 (forward, and data gradient with flipped
+// taps / transposed weights).  TAPS = 1: 1x1 with strided input / output pixel
+// maps -- the four (i,j) phases of the 2x2 stride-2 transposed convolution.
+//
+// wgrad_mfma_kernel<TAPS>: dW[tap][co][ci] = sum_pixel dZ[pixel][co] * X[pixel + off(tap)][ci]
+//   - the reduction runs over pixels, which is the strided dimension of both
+//     NHWC operands; ds_read_b64_tr_b16 (the transposing LDS read of gfx950)
+//     delivers the [pixel][channel] LDS tiles as K-contiguous MFMA fragments;
+//   - a workgroup owns a 64(co) x 64(ci) block of all TAPS filter taps and a
+//     slice of the pixels (split-K); partial blocks go to a workspace and a
+//     second kernel adds the slices in a fixed order (deterministic) while
+//     converting to the reference's [C_in][C_out][k][k] fp32 layout.
+#include "common.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef uint16_t bf16_t;
+
+namespace {
+
+__device__ __forceinline__ float bf16_to_f32(uint32_t h) { return __uint_as_float(h << 16); }
+__device__ __forceinline__ uint32_t f32_to_bf16(float f) {
+  __bf16 h = (__bf16)f;
+  return (uint32_t) __builtin_bit_cast(unsigned short, h);
+}
+
+struct ConvArgs {
+  const bf16_t *in;
+  const bf16_t *wt;
+  const float *bias;
+  bf16_t *out;
+  float *stats;  // [N][tiles][CoP][2] or null
+  int N, Hin, Win;       // input image size (pixels that may be addressed)
+  int Ho, Wo;            // logical pixel grid the tiles cover
+  int Ci, CoP;           // reduction channels (multiple of 32), output channels (multiple of BN)
+  int in_ld, out_ld;     // pixel strides in elements
+  int in_s, in_oy, in_ox;      // input pixel of logical (y,x): (y*in_s+in_oy, x*in_s+in_ox)  [TAPS==1]
+  int out_s, out_oy, out_ox;   // output pixel of logical (y,x)
+  int Hout, Wout;        // output image size
+  int accumulate;
+  int tilesX;
+  int co_valid;          // bias has this many entries
+};
+
+constexpr int PITCH = 80;  // bytes per LDS row of 32 bf16 (64 B payload + 16 B pad)
+
+template <int TAPS, int BN>
+__global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
+  constexpr int HALO = (TAPS == 9) ? 18 : 16;
+  constexpr int NPIX = HALO * HALO;
+  constexpr int W_BYTES = TAPS * BN * PITCH;
+  constexpr int XCH = NPIX * 4, XI = (XCH + 255) / 256;       // 16-byte pieces of the halo patch
+  constexpr int WCH = TAPS * BN * 4, WI = (WCH + 255) / 256;  // 16-byte pieces of the weight slice
+  constexpr int MF = BN / 32;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  unsigned char *ldsW = lds, *ldsX = lds + W_BYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tile = blockIdx.x, co0 = blockIdx.y * BN;
+  const i64 n = blockIdx.z;
+  const int y0 = (tile / a.tilesX) * 16, x0 = (tile % a.tilesX) * 16;
+  const bf16_t *in_n = a.in + n * (i64)a.Hin * a.Win * a.in_ld;
+
+  // per-thread staging plan (independent of the K chunk)
+  int xoff[XI];
+#pragma unroll
+  for (int i = 0; i < XI; ++i) {
+    const int c = tid + 256 * i, pix = c >> 2, part = c & 3;
+    const int py = pix / HALO, px = pix - py * HALO;
+    const int y = y0 + py - (TAPS == 9), x = x0 + px - (TAPS == 9);
+    const bool ok = c < XCH && y >= 0 && y < a.Ho && x >= 0 && x < a.Wo;
+    const int iy = (TAPS == 9) ? y : y * a.in_s + a.in_oy, ix = (TAPS == 9) ? x : x * a.in_s + a.in_ox;
+    xoff[i] = ok ? (iy * a.Win + ix) * a.in_ld + part * 8 : -1;
+  }
+  const bf16_t *w_thread = a.wt + (i64)co0 * a.Ci;  // + (tap*CoP + co)*Ci + part*8 + k0
+
+  uint4 xr[XI], wr[WI];
+  auto load_chunk = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < XI; ++i) {
+      xr[i] = make_uint4(0, 0, 0, 0);
+      if (xoff[i] >= 0) xr[i] = *reinterpret_cast<const uint4 *>(in_n + xoff[i] + k0);
+    }
+#pragma unroll
+    for (int i = 0; i < WI; ++i) {
+      const int c = tid + 256 * i, row = c >> 2, part = c & 3;
+      const int tap = row / BN, co = row % BN;
+      wr[i] = make_uint4(0, 0, 0, 0);
+      if (WCH % 256 == 0 || c < WCH)
+        wr[i] = *reinterpret_cast<const uint4 *>(w_thread + ((i64)tap * a.CoP + co) * a.Ci + k0 + part * 8);
+    }
+  };
+  auto store_chunk = [&]() {
+#pragma unroll
+    for (int i = 0; i < XI; ++i) {
+      const int c = tid + 256 * i;
+      if (XCH % 256 == 0 || c < XCH) *reinterpret_cast<uint4 *>(ldsX + (c >> 2) * PITCH + (c & 3) * 16) = xr[i];
+    }
+#pragma unroll
+    for (int i = 0; i < WI; ++i) {
+      const int c = tid + 256 * i;
+      if (WCH % 256 == 0 || c < WCH) *reinterpret_cast<uint4 *>(ldsW + (c >> 2) * PITCH + (c & 3) * 16) = wr[i];
+    }
+  };
+
+  f32x16 acc[MF][2];
+#pragma unroll
+  for (int m = 0; m < MF; ++m)
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][q][r] = 0.f;
+
+  const int a_lane = (lane & 31) * PITCH + (lane >> 5) * 16;
+  const int b_lane = ((wave * 4 + ((lane & 31) >> 4)) * HALO + (lane & 15)) * PITCH + (lane >> 5) * 16;
+
+  const int nk = a.Ci / 32;
+  load_chunk(0);
+  store_chunk();
+  __syncthreads();
+  for (int kc = 0; kc < nk; ++kc) {
+    if (kc + 1 < nk) load_chunk((kc + 1) * 32);
+#pragma unroll
+    for (int tap = 0; tap < TAPS; ++tap) {
+      const int kh = (TAPS == 9) ? tap / 3 : 0, kw = (TAPS == 9) ? tap % 3 : 0;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        bf16x8 af[MF], bfr[2];
+#pragma unroll
+        for (int m = 0; m < MF; ++m)
+          af[m] = *reinterpret_cast<const bf16x8 *>(ldsW + (tap * BN + m * 32) * PITCH + ks * 32 + a_lane);
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+          bfr[q] = *reinterpret_cast<const bf16x8 *>(ldsX + ((2 * q + kh) * HALO + kw) * PITCH + ks * 32 + b_lane);
+#pragma unroll
+        for (int m = 0; m < MF; ++m)
+#pragma unroll
+          for (int q = 0; q < 2; ++q)
+            acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[m], bfr[q], acc[m][q], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+    if (kc + 1 < nk) {
+      store_chunk();
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue: accumulators -> bf16 staging tile [256 pixels][BN] in LDS ----
+  constexpr int OP = BN * 2 + 16;  // staging row pitch in bytes
+  unsigned char *stage = lds;
+#pragma unroll
+  for (int m = 0; m < MF; ++m)
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int pix = wave * 64 + q * 32 + (lane & 31);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int ch = m * 32 + 8 * g + 4 * (lane >> 5);
+        f32x4 v = {acc[m][q][4 * g], acc[m][q][4 * g + 1], acc[m][q][4 * g + 2], acc[m][q][4 * g + 3]};
+        if (a.bias) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (co0 + ch + j < a.co_valid) v[j] += a.bias[co0 + ch + j];
+        }
+        const bf16x4 h = __builtin_convertvector(v, bf16x4);
+        *reinterpret_cast<bf16x4 *>(stage + pix * OP + ch * 2) = h;
+      }
+    }
+  __syncthreads();
+
+  // ---- per-tile batch-norm partial sums (of the rounded values) ----
+  if (a.stats) {
+    constexpr int CP = BN / 2;        // channel pairs
+    constexpr int SL = 256 / CP;      // pixel slices
+    constexpr int PPS = 256 / SL;     // pixels per slice
+    float *red = reinterpret_cast<float *>(lds + 256 * OP);
+    const int cp = tid % CP, sl = tid / CP;
+    float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
+    for (int i = 0; i < PPS; ++i) {
+      const int pix = sl * PPS + i;
+      if (y0 + (pix >> 4) < a.Ho && x0 + (pix & 15) < a.Wo) {
+        const uint32_t u = *reinterpret_cast<const uint32_t *>(stage + pix * OP + cp * 4);
+        const float v0 = bf16_to_f32(u & 0xffffu), v1 = bf16_to_f32(u >> 16);
+        s0 += v0; q0 += v0 * v0; s1 += v1; q1 += v1 * v1;
+      }
+    }
+    *reinterpret_cast<f32x4 *>(red + (sl * CP + cp) * 4) = f32x4{s0, q0, s1, q1};
+    __syncthreads();
+    if (tid < BN) {
+      const int c2 = tid >> 1, odd = tid & 1;
+      float s = 0.f, q = 0.f;
+      for (int j = 0; j < SL; ++j) {
+        s += red[(j * CP + c2) * 4 + 2 * odd];
+        q += red[(j * CP + c2) * 4 + 2 * odd + 1];
+      }
+      float *dst = a.stats + ((n * gridDim.x + tile) * (i64)a.CoP + co0 + tid) * 2;
+      dst[0] = s;
+      dst[1] = q;
+    }
+  }
+
+  // ---- staging tile -> HBM, 16 bytes per lane, whole channel rows ----
+  constexpr int CH = BN / 8;  // 16-byte pieces per pixel
+  bf16_t *out_n = a.out + n * (i64)a.Hout * a.Wout * a.out_ld + co0;
+#pragma unroll
+  for (int i = 0; i < CH; ++i) {
+    const int c = tid + 256 * i, pix = c / CH, part = c % CH;
+    const int y = y0 + (pix >> 4), x = x0 + (pix & 15);
+    if (y < a.Ho && x < a.Wo) {
+      uint4 v = *reinterpret_cast<const uint4 *>(stage + pix * OP + part * 16);
+      bf16_t *dst = out_n + ((i64)(y * a.out_s + a.out_oy) * a.Wout + (x * a.out_s + a.out_ox)) * a.out_ld + part * 8;
+      if (a.accumulate) {
+        const uint4 o = *reinterpret_cast<const uint4 *>(dst);
+        const uint32_t vv[4] = {v.x, v.y, v.z, v.w}, oo[4] = {o.x, o.y, o.z, o.w};
+        uint32_t rr[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float lo = bf16_to_f32(vv[j] & 0xffffu) + bf16_to_f32(oo[j] & 0xffffu);
+          const float hi = bf16_to_f32(vv[j] >> 16) + bf16_to_f32(oo[j] >> 16);
+          rr[j] = f32_to_bf16(lo) | (f32_to_bf16(hi) << 16);
+        }
+        v = make_uint4(rr[0], rr[1], rr[2], rr[3]);
+      }
+      *reinterpret_cast<uint4 *>(dst) = v;
+    }
+  }
+}
+
+template <int TAPS, int BN>
+constexpr size_t conv_lds_bytes() {
+  constexpr int HALO = (TAPS == 9) ? 18 : 16;
+  constexpr size_t main_loop = (size_t)TAPS * BN * PITCH + (size_t)HALO * HALO * PITCH;
+  constexpr size_t epilogue = (size_t)256 * (BN * 2 + 16) + 4096;
+  return main_loop > epilogue ? main_loop : epilogue;
+}
+
+template <int TAPS, int BN>
+int launch_conv(const ConvArgs &a, hipStream_t s) {
+  static bool attr_set[64] = {};
+  constexpr size_t lds = conv_lds_bytes<TAPS, BN>();
+  int dev = 0;
+  UNET_HIP_TRY(hipGetDevice(&dev));
+  if (!attr_set[dev & 63]) {
+    UNET_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_mfma_kernel<TAPS, BN>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set[dev & 63] = true;
+  }
+  const int tilesY = (a.Ho + 15) / 16;
+  dim3 grid((unsigned)(tilesY * a.tilesX), (unsigned)(a.CoP / BN), (unsigned)a.N);
+  hipLaunchKernelGGL((conv_mfma_kernel<TAPS, BN>), grid, dim3(256), lds, s, a);
+  UNET_LAUNCH_CHECK("conv_mfma_kernel");
+  return UNET_OK;
+}
+
+int launch_conv_any(int taps, const ConvArgs &a, hipStream_t s) {
+  if (taps == 9) return (a.CoP % 64 == 0) ? launch_conv<9, 64>(a, s) : launch_conv<9, 32>(a, s);
+  return (a.CoP % 64 == 0) ? launch_conv<1, 64>(a, s) : launch_conv<1, 32>(a, s);
+}
+
+// ---------------------------------------------------------------------------
+// Weight gradient.
+// ---------------------------------------------------------------------------
+struct WgradArgs {
+  const bf16_t *dz;  // [N][Hz][Wz][dz_ld], CoP channels used
+  const bf16_t *x;   // [N][H][W][x_ld], CiP channels used
+  float *partial;    // [splits][TAPS][CoP][CiP] fp32
+  int N, H, W;       // logical pixel grid = x image size
+  int Hz, Wz;        // dz image size
+  int dz_ld, x_ld, CoP, CiP;  // partial-buffer dims (multiples of 64)
+  int z_c, x_c;               // channels present in dz / x (multiples of 8)
+  int dz_s, dz_oy, dz_ox;  // dz pixel of logical (y,x): (y*dz_s+dz_oy, x*dz_s+dz_ox)
+  int chunksX, chunksY;    // 8x16 pixel chunks per image
+  int chunks_per_split, total_chunks;
+};
+
+__device__ __forceinline__ bf16x8 tr_read_pair(const unsigned char *p0, const unsigned char *p1) {
+  // two transposing 64-bit LDS reads -> one 8-element K-contiguous MFMA fragment
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (__attribute__((address_space(3))) s16x4 *)(__attribute__((address_space(3))) void *)(p0));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (__attribute__((address_space(3))) s16x4 *)(__attribute__((address_space(3))) void *)(p1));
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+constexpr int WP = 192;  // LDS row pitch (bytes) of a 64-channel pixel row: 4 rows x 64 B fall in 4 distinct bank quarters
+
+template <int TAPS>
+__global__ __launch_bounds__(256, 1) void wgrad_mfma_kernel(const WgradArgs a) {
+  constexpr int XR = (TAPS == 9) ? 10 : 8, XC = (TAPS == 9) ? 18 : 16;  // x patch (with halo for 3x3)
+  constexpr int XPIX = XR * XC, ZPIX = 128;
+  constexpr int XCH = XPIX * 8, XI = (XCH + 255) / 256;  // 16-byte pieces (8 per 64-channel row)
+  constexpr int ZCH = ZPIX * 8, ZI = ZCH / 256;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  unsigned char *ldsZ = lds, *ldsX = lds + ZPIX * WP;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int co0 = blockIdx.y * 64, ci0 = blockIdx.z * 64, split = blockIdx.x;
+  const int wm = wave >> 1, wn = wave & 1;  // wave's 32x32 block of the 64(co) x 64(ci) tile
+
+  f32x16 acc[TAPS];
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  // transposing-read lane addresses: lane 4q+p of each 16-lane group supplies row q, 4-channel piece p
+  const int grp = lane >> 4, li = lane & 15, q = li >> 2, p = li & 3, h = grp >> 1;
+  const int z_lane = (8 * h + q) * WP + (wm * 32 + 16 * (grp & 1) + 4 * p) * 2;
+  const int x_lane = (8 * h + q) * WP + (wn * 32 + 16 * (grp & 1) + 4 * p) * 2;
+
+  const int c_begin = split * a.chunks_per_split;
+  const int c_end = min(a.total_chunks, c_begin + a.chunks_per_split);
+  const int per_img = a.chunksX * a.chunksY;
+
+  uint4 xr[XI], zr[ZI];
+  auto load_chunk = [&](int chunk) {
+    const int n = chunk / per_img, r = chunk - n * per_img;
+    const int y0 = (r / a.chunksX) * 8, x0 = (r % a.chunksX) * 16;
+    const bf16_t *x_n = a.x + (i64)n * a.H * a.W * a.x_ld + ci0;
+    const bf16_t *z_n = a.dz + (i64)n * a.Hz * a.Wz * a.dz_ld + co0;
+#pragma unroll
+    for (int i = 0; i < XI; ++i) {
+      const int c = tid + 256 * i, pix = c >> 3, part = c & 7;
+      const int py = pix / XC, px = pix - py * XC;
+      const int y = y0 + py - (TAPS == 9), x = x0 + px - (TAPS == 9);
+      xr[i] = make_uint4(0, 0, 0, 0);
+      if ((XCH % 256 == 0 || c < XCH) && y >= 0 && y < a.H && x >= 0 && x < a.W && ci0 + part * 8 < a.x_c)
+        xr[i] = *reinterpret_cast<const uint4 *>(x_n + ((i64)y * a.W + x) * a.x_ld + part * 8);
+    }
+#pragma unroll
+    for (int i = 0; i < ZI; ++i) {
+      const int c = tid + 256 * i, pix = c >> 3, part = c & 7;
+      const int y = y0 + (pix >> 4), x = x0 + (pix & 15);
+      zr[i] = make_uint4(0, 0, 0, 0);
+      if (y < a.H && x < a.W && co0 + part * 8 < a.z_c)
+        zr[i] = *reinterpret_cast<const uint4 *>(
+            z_n + ((i64)(y * a.dz_s + a.dz_oy) * a.Wz + (x * a.dz_s + a.dz_ox)) * a.dz_ld + part * 8);
+    }
+  };
+  auto store_chunk = [&]() {
+#pragma unroll
+    for (int i = 0; i < XI; ++i) {
+      const int c = tid + 256 * i;
+      if (XCH % 256 == 0 || c < XCH) *reinterpret_cast<uint4 *>(ldsX + (c >> 3) * WP + (c & 7) * 16) = xr[i];
+    }
+#pragma unroll
+    for (int i = 0; i < ZI; ++i) {
+      const int c = tid + 256 * i;
+      *reinterpret_cast<uint4 *>(ldsZ + (c >> 3) * WP + (c & 7) * 16) = zr[i];
+    }
+  };
+
+  if (c_begin < c_end) {
+    load_chunk(c_begin);
+    store_chunk();
+    __syncthreads();
+    for (int chunk = c_begin; chunk < c_end; ++chunk) {
+      if (chunk + 1 < c_end) load_chunk(chunk + 1);
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {  // K step = one 16-pixel row of the 8x16 chunk
+        const unsigned char *zp = ldsZ + ks * 16 * WP + z_lane;
+        const bf16x8 af = tr_read_pair(zp, zp + 4 * WP);
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t) {
+          const int kh = (TAPS == 9) ? t / 3 : 0, kw = (TAPS == 9) ? t % 3 : 0;
+          const unsigned char *xp = ldsX + ((ks + kh) * XC + kw) * WP + x_lane;
+          const bf16x8 bfr = tr_read_pair(xp, xp + 4 * WP);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, acc[t], 0, 0, 0);
+        }
+      }
+      __syncthreads();
+      if (chunk + 1 < c_end) {
+        store_chunk();
+        __syncthreads();
+      }
+    }
+  }
+  // partial[split][tap][co][ci]; accumulator reg r: co = (r&3) + 8*(r>>2) + 4*(lane>>5), ci = lane&31
+  float *dst = a.partial + (((i64)split * TAPS) * a.CoP + co0 + wm * 32) * a.CiP + ci0 + wn * 32 + (lane & 31);
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      dst[((i64)t * a.CoP + row) * a.CiP] = acc[t][r];
+    }
+}
+
+// grad[(ci*Co + co)*taps_total + tap_index(t)] (+)= sum_split partial[split][t][co][ci]
+// tap_index: for 3x3, t; for the transposed conv phases, tap_base (one phase per launch).
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restrict__ partial,
+                                                           float *__restrict__ grad, int splits, int taps,
+                                                           int CoP, int CiP, int Co, int Ci, int taps_total,
+                                                           int tap_base) {
+  const i64 total = (i64)taps * Co * Ci;
+  for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (i64)gridDim.x * blockDim.x) {
+    const int ci = (int)(i % Ci);
+    const i64 r = i / Ci;
+    const int co = (int)(r % Co), t = (int)(r / Co);
+    double s = 0;
+    for (int k = 0; k < splits; ++k) s += partial[(((i64)k * taps + t) * CoP + co) * CiP + ci];
+    grad[((i64)ci * Co + co) * taps_total + tap_base + t] = (float)s;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Weight packing and layout conversion.
+// ---------------------------------------------------------------------------
+// w_ref [Ci][Co][K][K] fp32 ->
+//   fwd [tap][CoP][CiP] bf16 (tap = kh*K+kw), zero padded
+//   bwd [tap][CiP][CoP] bf16 with flipped taps for K=3 (data gradient as a forward conv over dZ);
+//       unflipped for the transposed-conv phases (K=2, taps are the (i,j) phases)
+__global__ __launch_bounds__(256) void pack_weights_kernel(const float *__restrict__ w, bf16_t *__restrict__ fwd,
+                                                           bf16_t *__restrict__ bwd, int Ci, int Co, int CiP,
+                                                           int CoP, int K) {
+  const int taps = K * K;
+  const i64 total = (i64)taps * CoP * CiP;
+  for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (i64)gridDim.x * blockDim.x) {
+    const int ci = (int)(i % CiP);
+    const i64 r = i / CiP;
+    const int co = (int)(r % CoP), t = (int)(r / CoP);
+    float v = 0.f;
+    if (ci < Ci && co < Co) v = w[((i64)ci * Co + co) * taps + t];
+    const bf16_t hv = (bf16_t)f32_to_bf16(v);
+    if (fwd) fwd[i] = hv;
+    if (bwd) {
+      const int tb = (K == 3) ? (taps - 1 - t) : t;
+      bwd[((i64)tb * CiP + ci) * CoP + co] = hv;
+    }
+  }
+}
+
+// NCHW fp32 -> NHWC bf16 with pixel stride ld; channels [C, Cpad) are zero-filled.
+// One block transposes a 32-pixel x 32-channel tile through LDS.
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float *__restrict__ in, bf16_t *__restrict__ out,
+                                                           int C, i64 HW, int ld, int Cpad) {
+  __shared__ float t[32][33];
+  const i64 n = blockIdx.z;
+  const i64 p0 = (i64)blockIdx.x * 32;
+  const int c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 8 rows of 32
+  for (int r = ty; r < 32; r += 8) {
+    const int c = c0 + r;
+    const i64 p = p0 + tx;
+    t[r][tx] = (c < C && p < HW) ? in[(n * C + c) * HW + p] : 0.f;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const i64 p = p0 + r;
+    const int c = c0 + tx;
+    if (p < HW && c < Cpad) out[(n * HW + p) * ld + c] = (bf16_t)f32_to_bf16(t[tx][r]);
+  }
+}
+
+// NHWC bf16 (pixel stride ld) -> NCHW fp32, channels [0, C)
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const bf16_t *__restrict__ in, float *__restrict__ out,
+                                                           int C, i64 HW, int ld) {
+  __shared__ float t[32][33];
+  const i64 n = blockIdx.z;
+  const i64 p0 = (i64)blockIdx.x * 32;
+  const int c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int r = ty; r < 32; r += 8) {
+    const i64 p = p0 + r;
+    const int c = c0 + tx;
+    t[r][tx] = (p < HW && c < C) ? bf16_to_f32(in[(n * HW + p) * ld + c]) : 0.f;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int c = c0 + r;
+    const i64 p = p0 + tx;
+    if (c < C && p < HW) out[(n * C + c) * HW + p] = t[tx][r];
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int unet_pack_weights_bf16(const float *w_ref, uint16_t *w_fwd, uint16_t *w_bwd, int Ci, int Co, int CiP,
+                           int CoP, int K, unet_stream_t s) {
+  UNET_REQUIRE(w_ref && (w_fwd || w_bwd), "unet_pack_weights_bf16: NULL pointer");
+  UNET_REQUIRE(Ci > 0 && Co > 0 && CiP >= Ci && CoP >= Co && (K == 3 || K == 2) && CiP % 32 == 0 && CoP % 32 == 0,
+               "unet_pack_weights_bf16: need K in {2,3} and padded channel counts that are multiples of 32");
+  const i64 total = (i64)K * K * CoP * CiP;
+  hipLaunchKernelGGL(pack_weights_kernel, dim3(ew_grid(total)), dim3(256), 0, as_stream(s), w_ref, w_fwd, w_bwd, Ci,
+                     Co, CiP, CoP, K);
+  UNET_LAUNCH_CHECK("pack_weights_kernel");
+  return UNET_OK;
+}
+
+int unet_nchw_f32_to_nhwc_bf16(const float *in, uint16_t *out, int N, int C, int H, int W, int ld, int Cpad,
+                               unet_stream_t s) {
+  UNET_REQUIRE(in && out, "unet_nchw_f32_to_nhwc_bf16: NULL pointer");
+  UNET_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0 && Cpad >= C && ld >= Cpad && N <= 65535,
+               "unet_nchw_f32_to_nhwc_bf16: bad sizes");
+  const i64 HW = (i64)H * W;
+  dim3 grid(cdiv_u(HW, 32), cdiv_u(Cpad, 32), (unsigned)N);
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel, grid, dim3(256), 0, as_stream(s), in, out, C, HW, ld, Cpad);
+  UNET_LAUNCH_CHECK("nchw_to_nhwc_kernel");
+  return UNET_OK;
+}
+
+int unet_nhwc_bf16_to_nchw_f32(const uint16_t *in, float *out, int N, int C, int H, int W, int ld,
+                               unet_stream_t s) {
+  UNET_REQUIRE(in && out, "unet_nhwc_bf16_to_nchw_f32: NULL pointer");
+  UNET_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0 && ld >= C && N <= 65535, "unet_nhwc_bf16_to_nchw_f32: bad sizes");
+  const i64 HW = (i64)H * W;
+  dim3 grid(cdiv_u(HW, 32), cdiv_u(C, 32), (unsigned)N);
+  hipLaunchKernelGGL(nhwc_to_nchw_kernel, grid, dim3(256), 0, as_stream(s), in, out, C, HW, ld);
+  UNET_LAUNCH_CHECK("nhwc_to_nchw_kernel");
+  return UNET_OK;
+}
+
+int unet_conv3x3_bf16(const uint16_t *in, int in_ld, const uint16_t *w_packed, const float *bias, int co_valid,
+                      uint16_t *out, int out_ld, float *stat_partials, int N, int H, int W, int CiP, int CoP,
+                      int accumulate, unet_stream_t s) {
+  UNET_REQUIRE(in && w_packed && out, "unet_conv3x3_bf16: NULL pointer");
+  UNET_REQUIRE(N > 0 && N <= 65535 && H > 0 && W > 0, "unet_conv3x3_bf16: bad sizes");
+  UNET_REQUIRE(CiP > 0 && CiP % 32 == 0 && CoP > 0 && CoP % 32 == 0 && in_ld >= CiP && out_ld >= CoP &&
+                   in_ld % 8 == 0 && out_ld % 8 == 0,
+               "unet_conv3x3_bf16: channel counts must be multiples of 32 and pixel strides multiples of 8");
+  UNET_REQUIRE((((uintptr_t)in | (uintptr_t)out | (uintptr_t)w_packed) & 15) == 0,
+               "unet_conv3x3_bf16: pointers must be 16-byte aligned");
+  UNET_REQUIRE((i64)H * W * in_ld < (1ll << 31) && (i64)H * W * out_ld < (1ll << 31),
+               "unet_conv3x3_bf16: one image must stay below 2^31 elements");
+  ConvArgs a{};
+  a.in = in; a.wt = w_packed; a.bias = bias; a.out = out; a.stats = stat_partials;
+  a.N = N; a.Hin = H; a.Win = W; a.Ho = H; a.Wo = W; a.Ci = CiP; a.CoP = CoP;
+  a.in_ld = in_ld; a.out_ld = out_ld; a.in_s = 1; a.in_oy = a.in_ox = 0;
+  a.out_s = 1; a.out_oy = a.out_ox = 0; a.Hout = H; a.Wout = W; a.accumulate = accumulate;
+  a.tilesX = (W + 15) / 16;
+  a.co_valid = co_valid;
+  const double flops = 2.0 * N * H * W * (double)CiP * CoP * 9;
+  ProfScope prof(stat_partials || bias ? PROF_CONV_FWD_BF16 : PROF_CONV_DGRAD_BF16, flops,
+                 2.0 * N * H * W * ((double)CiP + CoP), as_stream(s));
+  return launch_conv_any(9, a, as_stream(s));
+}
+
+int unet_conv3x3_stat_tiles(int H, int W) { return ((H + 15) / 16) * ((W + 15) / 16); }
+
+// One (i,j) phase launch per call is an implementation detail: these entry
+// points run all four phases of the 2x2 stride-2 transposed convolution.
+int unet_tconv2x2_bf16(const uint16_t *in, int in_ld, const uint16_t *w_packed, const float *bias, int co_valid,
+                       uint16_t *out, int out_ld, float *stat_partials, int N, int H_in, int W_in, int CiP, int CoP,
+                       unet_stream_t s) {
+  UNET_REQUIRE(in && w_packed && out, "unet_tconv2x2_bf16: NULL pointer");
+  UNET_REQUIRE(N > 0 && N <= 65535 && H_in > 0 && W_in > 0, "unet_tconv2x2_bf16: bad sizes");
+  UNET_REQUIRE(CiP > 0 && CiP % 32 == 0 && CoP > 0 && CoP % 32 == 0 && in_ld >= CiP && out_ld >= CoP &&
+                   in_ld % 8 == 0 && out_ld % 8 == 0,
+               "unet_tconv2x2_bf16: channel counts must be multiples of 32 and pixel strides multiples of 8");
+  UNET_REQUIRE((i64)H_in * W_in * in_ld < (1ll << 31) && (i64)4 * H_in * W_in * out_ld < (1ll << 31),
+               "unet_tconv2x2_bf16: one image must stay below 2^31 elements");
+  const int tiles = unet_conv3x3_stat_tiles(H_in, W_in);
+  ProfScope prof(PROF_TCONV_BF16, 2.0 * N * H_in * W_in * 4.0 * CiP * CoP,
+                 2.0 * N * H_in * W_in * ((double)CiP + 4.0 * CoP), as_stream(s));
+  for (int ph = 0; ph < 4; ++ph) {
+    ConvArgs a{};
+    a.in = in; a.wt = w_packed + (i64)ph * CoP * CiP; a.bias = bias; a.out = out;
+    a.stats = stat_partials ? stat_partials + (i64)ph * N * tiles * CoP * 2 : nullptr;
+    a.N = N; a.Hin = H_in; a.Win = W_in; a.Ho = H_in; a.Wo = W_in; a.Ci = CiP; a.CoP = CoP;
+    a.in_ld = in_ld; a.out_ld = out_ld; a.in_s = 1; a.in_oy = a.in_ox = 0;
+    a.out_s = 2; a.out_oy = ph >> 1; a.out_ox = ph & 1; a.Hout = 2 * H_in; a.Wout = 2 * W_in; a.accumulate = 0;
+    a.tilesX = (W_in + 15) / 16;
+    a.co_valid = co_valid;
+    int rc = launch_conv_any(1, a, as_stream(s));
+    if (rc) return rc;
+  }
+  return UNET_OK;
+}
+
+// dX[n,h,w,ci] = sum_{i,j} sum_co dY[n,2h+i,2w+j,co] * W[ci,co,i,j];  w_packed_bwd = [phase][CiP][CoP]
+int unet_tconv2x2_dgrad_bf16(const uint16_t *dy, int dy_ld, const uint16_t *w_packed_bwd, uint16_t *dx, int dx_ld,
+                             int N, int H_in, int W_in, int CiP, int CoP, int accumulate, unet_stream_t s) {
+  UNET_REQUIRE(dy && w_packed_bwd && dx, "unet_tconv2x2_dgrad_bf16: NULL pointer");
+  UNET_REQUIRE(N > 0 && N <= 65535 && H_in > 0 && W_in > 0, "unet_tconv2x2_dgrad_bf16: bad sizes");
+  UNET_REQUIRE(CiP > 0 && CiP % 32 == 0 && CoP > 0 && CoP % 32 == 0 && dy_ld >= CoP && dx_ld >= CiP &&
+                   dy_ld % 8 == 0 && dx_ld % 8 == 0,
+               "unet_tconv2x2_dgrad_bf16: channel counts must be multiples of 32 and pixel strides multiples of 8");
+  UNET_REQUIRE((i64)4 * H_in * W_in * dy_ld < (1ll << 31) && (i64)H_in * W_in * dx_ld < (1ll << 31),
+               "unet_tconv2x2_dgrad_bf16: one image must stay below 2^31 elements");
+  ProfScope prof(PROF_TCONV_BF16, 2.0 * N * H_in * W_in * 4.0 * CiP * CoP,
+                 2.0 * N * H_in * W_in * ((double)CiP + 4.0 * CoP), as_stream(s));
+  for (int ph = 0; ph < 4; ++ph) {
+    ConvArgs a{};
+    a.in = dy; a.wt = w_packed_bwd + (i64)ph * CiP * CoP; a.bias = nullptr; a.out = dx; a.stats = nullptr;
+    a.N = N; a.Hin = 2 * H_in; a.Win = 2 * W_in; a.Ho = H_in; a.Wo = W_in; a.Ci = CoP; a.CoP = CiP;
+    a.in_ld = dy_ld; a.out_ld = dx_ld; a.in_s = 2; a.in_oy = ph >> 1; a.in_ox = ph & 1;
+    a.out_s = 1; a.out_oy = a.out_ox = 0; a.Hout = H_in; a.Wout = W_in; a.accumulate = (ph > 0) || accumulate;
+    a.tilesX = (W_in + 15) / 16;
+    int rc = launch_conv_any(1, a, as_stream(s));
+    if (rc) return rc;
+  }
+  return UNET_OK;
+}
+
+static int run_wgrad(int taps, const WgradArgs &base, float *grad, int Ci, int Co, int taps_total, int tap_base,
+                     hipStream_t s) {
+  WgradArgs a = base;
+  a.chunksX = (a.W + 15) / 16;
+  a.chunksY = (a.H + 7) / 8;
+  a.total_chunks = a.N * a.chunksX * a.chunksY;
+  const int tiles = (a.CoP / 64) * (a.CiP / 64);
+  int splits = (1024 + tiles - 1) / tiles;
+  if (splits > a.total_chunks) splits = a.total_chunks;
+  if (splits < 1) splits = 1;
+  a.chunks_per_split = (a.total_chunks + splits - 1) / splits;
+  splits = (a.total_chunks + a.chunks_per_split - 1) / a.chunks_per_split;
+  void *ws;
+  int rc = unet_workspace(&ws, sizeof(float) * (size_t)splits * taps * a.CoP * a.CiP);
+  if (rc) return rc;
+  a.partial = (float *)ws;
+  const size_t lds = (size_t)128 * WP + (size_t)(taps == 9 ? 180 : 128) * WP;
+  static bool attr_set[2][64] = {};
+  int dev = 0;
+  UNET_HIP_TRY(hipGetDevice(&dev));
+  if (!attr_set[taps == 9][dev & 63]) {
+    if (taps == 9)
+      UNET_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&wgrad_mfma_kernel<9>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    else
+      UNET_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&wgrad_mfma_kernel<1>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set[taps == 9][dev & 63] = true;
+  }
+  dim3 grid((unsigned)splits, (unsigned)(a.CoP / 64), (unsigned)(a.CiP / 64));
+  if (taps == 9)
+    hipLaunchKernelGGL(wgrad_mfma_kernel<9>, grid, dim3(256), lds, s, a);
+  else
+    hipLaunchKernelGGL(wgrad_mfma_kernel<1>, grid, dim3(256), lds, s, a);
+  UNET_LAUNCH_CHECK("wgrad_mfma_kernel");
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ew_grid((i64)taps * Co * Ci)), dim3(256), 0, s, (const float *)ws, grad,
+                     splits, taps, a.CoP, a.CiP, Co, Ci, taps_total, tap_base);
+  UNET_LAUNCH_CHECK("wgrad_reduce_kernel");
+  return UNET_OK;
+}
+
+// grad_w [Ci][Co][3][3] fp32 (reference layout, overwritten)
+int unet_conv3x3_wgrad_bf16(const uint16_t *dz, int dz_ld, const uint16_t *x, int x_ld, float *grad_w, int N, int H,
+                            int W, int CiP, int CoP, int Ci, int Co, unet_stream_t s) {
+  UNET_REQUIRE(dz && x && grad_w, "unet_conv3x3_wgrad_bf16: NULL pointer");
+  UNET_REQUIRE(N > 0 && H > 0 && W > 0 && Ci > 0 && Co > 0 && Ci <= CiP && Co <= CoP,
+               "unet_conv3x3_wgrad_bf16: bad sizes");
+  UNET_REQUIRE(CiP % 8 == 0 && CoP % 8 == 0 && dz_ld >= CoP && x_ld >= CiP && dz_ld % 8 == 0 && x_ld % 8 == 0,
+               "unet_conv3x3_wgrad_bf16: padded channel counts and pixel strides must be multiples of 8");
+  WgradArgs a{};
+  a.dz = dz; a.x = x; a.N = N; a.H = H; a.W = W; a.Hz = H; a.Wz = W; a.dz_ld = dz_ld; a.x_ld = x_ld;
+  a.CoP = (CoP + 63) / 64 * 64; a.CiP = (CiP + 63) / 64 * 64; a.z_c = CoP; a.x_c = CiP;
+  a.dz_s = 1; a.dz_oy = a.dz_ox = 0;
+  ProfScope prof(PROF_CONV_WGRAD_BF16, 2.0 * N * H * W * (double)CiP * CoP * 9, 2.0 * N * H * W * ((double)CiP + CoP),
+                 as_stream(s));
+  return run_wgrad(9, a, grad_w, Ci, Co, 9, 0, as_stream(s));
+}
+
+// grad_w [Ci][Co][2][2] fp32 (overwritten); x = the transposed conv's input, dy its output gradient
+int unet_tconv2x2_wgrad_bf16(const uint16_t *dy, int dy_ld, const uint16_t *x, int x_ld, float *grad_w, int N,
+                             int H_in, int W_in, int CiP, int CoP, int Ci, int Co, unet_stream_t s) {
+  UNET_REQUIRE(dy && x && grad_w, "unet_tconv2x2_wgrad_bf16: NULL pointer");
+  UNET_REQUIRE(N > 0 && H_in > 0 && W_in > 0 && Ci > 0 && Co > 0 && Ci <= CiP && Co <= CoP,
+               "unet_tconv2x2_wgrad_bf16: bad sizes");
+  UNET_REQUIRE(CiP % 8 == 0 && CoP % 8 == 0 && dy_ld >= CoP && x_ld >= CiP && dy_ld % 8 == 0 && x_ld % 8 == 0,
+               "unet_tconv2x2_wgrad_bf16: padded channel counts and pixel strides must be multiples of 8");
+  ProfScope prof(PROF_TCONV_BF16, 2.0 * N * H_in * W_in * 4.0 * CiP * CoP,
+                 2.0 * N * H_in * W_in * ((double)CiP + 4.0 * CoP), as_stream(s));
+  for (int ph = 0; ph < 4; ++ph) {
+    WgradArgs a{};
+    a.dz = dy; a.x = x; a.N = N; a.H = H_in; a.W = W_in; a.Hz = 2 * H_in; a.Wz = 2 * W_in;
+    a.dz_ld = dy_ld; a.x_ld = x_ld; a.CoP = (CoP + 63) / 64 * 64; a.CiP = (CiP + 63) / 64 * 64;
+    a.z_c = CoP; a.x_c = CiP; a.dz_s = 2; a.dz_oy = ph >> 1; a.dz_ox = ph & 1;
+    int rc = run_wgrad(1, a, grad_w, Ci, Co, 4, ph, as_stream(s));
+    if (rc) return rc;
+  }
+  return UNET_OK;
+}
+
+}  // extern "C"
