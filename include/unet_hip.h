@@ -306,6 +306,41 @@ int unet_tconv2x2_dgrad_bf16(const uint16_t *dy, int dy_ld, const uint16_t *w_pa
 int unet_tconv2x2_wgrad_bf16(const uint16_t *dy, int dy_ld, const uint16_t *x, int x_ld, float *grad_w, int N,
                              int H_in, int W_in, int CiP, int CoP, int Ci, int Co, unet_stream_t stream);
 
+
+/* Batch norm on NHWC bf16 tensors.  `coef` is a device array of
+ * unet_bn_coef_floats(CoP) floats written by unet_bn_finalize_bf16 (training:
+ * batch statistics from the convolution's per-tile partial sums; also writes
+ * the raw sums to batch_stats[2C] and updates running_stats[2C] like
+ * cudaBatchNormTrain) or unet_bn_inference_coef_bf16 (running statistics) and
+ * read by the apply / backward kernels.  `count` = N*H*W. */
+int unet_bn_coef_floats(int CoP);
+int unet_bn_finalize_bf16(const float *stat_partials, int num_partials, int C, int CoP, int64_t count,
+                          const float *gamma_beta, float *batch_stats, float *running_stats, float *coef,
+                          unet_stream_t stream);
+int unet_bn_inference_coef_bf16(const float *gamma_beta, const float *running_stats, int C, int CoP, float *coef,
+                                unet_stream_t stream);
+/* y = act(gamma*(z-mean)/(sqrt(var)+eps)+beta): the normalise half of
+ * cudaBatchNormTrain / cudaBatchNormInference fused with cudaRelu (act 0),
+ * cudaSigmoid (act 1) or nothing (act 2).  y may be a channel slice of a
+ * concat buffer (y_ld > CoP). */
+int unet_bn_act_bf16(const uint16_t *z, int z_ld, uint16_t *y, int y_ld, const float *coef, int CoP,
+                     int64_t pixels, int act, unet_stream_t stream);
+/* cudaReluBackward|cudaSigmoidBackward + cudaBatchNormBackward fused: the
+ * incoming gradient is dy1 (+ dy2 when not NULL: gradient fan-in of a layer
+ * with two consumers, replacing cudaAddBtoA); writes dz (bf16), grad_gb[2C]
+ * = [dgamma,dbeta] interleaved and, when not NULL, grad_bias[C] = sum dz. */
+int unet_bn_act_backward_bf16(const uint16_t *dy1, int ld1, const uint16_t *dy2, int ld2, const uint16_t *z, int z_ld,
+                              const float *coef, const float *gamma_beta, uint16_t *dz, int dz_ld, float *grad_gb,
+                              float *grad_bias, int C, int CoP, int64_t pixels, int act, unet_stream_t stream);
+
+/* 2x2 stride-2 max pool on NHWC bf16 (cudaMaxPool) that also saves a tie mask:
+ * mask[n,ho,wo,c] bit (2i+j) is set when x[n,2ho+i,2wo+j,c] equals the maximum.
+ * The backward (cudaMaxPoolBackward) routes dy to every set bit. */
+int unet_max_pool2x2_bf16(const uint16_t *x, int x_ld, uint16_t *y, int y_ld, uint8_t *mask, int N, int H, int W,
+                          int C, unet_stream_t stream);
+int unet_max_pool2x2_backward_bf16(const uint16_t *dy, int dy_ld, const uint8_t *mask, uint16_t *dx, int dx_ld, int N,
+                                   int H, int W, int C, int accumulate, unet_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -179,3 +179,113 @@ def test_tconv2x2(G, capi, oracle, cfg):
     ref = dw_ref[:ci * co * 4]
     got = G.host(gw)
     assert np.abs(got - ref).max() <= 1e-3 * np.abs(ref).max(), (np.abs(got - ref).max(), np.abs(ref).max())
+
+
+# ------------------------------------------------ fused BN / activation ----
+def nhwc_tensor(G, x, ld=None):
+    """x [N,C,H,W] float (bf16-representable) -> NHWC bf16 device tensor with pixel stride ld."""
+    n, c, h, w = x.shape
+    ld = ld or c
+    t = torch.zeros((n, h, w, ld), dtype=torch.bfloat16, device=G.DEV)
+    t[..., :c] = torch.from_numpy(np.ascontiguousarray(x.transpose(0, 2, 3, 1))).to(G.DEV).bfloat16()
+    return t
+
+
+def nchw(t, c):
+    return t[..., :c].float().cpu().numpy().transpose(0, 3, 1, 2)
+
+
+@pytest.mark.parametrize("cfg", [(2, 64, 16, 16, 0), (1, 32, 9, 7, 0), (3, 96, 8, 8, 0), (2, 32, 8, 8, 1),
+                                 (1, 256, 4, 4, 2), (2, 24, 6, 6, 0)])
+def test_bn_act_forward_backward(G, capi, oracle, cfg):
+    n, c, h, w, act = cfg
+    cop = (c + 7) // 8 * 8
+    rng = np.random.default_rng(c * 10 + act)
+    z = bf16_round(rng.standard_normal((n, c, h, w)) * 1.3 + 0.4)
+    gb = (rng.standard_normal(2 * c) * 0.5 + np.tile([1.0, 0.0], c)).astype(np.float32)
+    run_in = np.abs(rng.standard_normal(2 * c)).astype(np.float32)
+    dy1 = bf16_round(rng.standard_normal((n, c, h, w)))
+    dy2 = bf16_round(rng.standard_normal((n, c, h, w)))
+    M = n * h * w
+    # partial sums as the convolution epilogue would deliver them (two slices to exercise the reduction)
+    half = z[:, :, : h // 2], z[:, :, h // 2:]
+    partial = np.zeros((2, cop, 2), np.float32)
+    for i, part in enumerate(half):
+        partial[i, :c, 0] = part.sum(axis=(0, 2, 3))
+        partial[i, :c, 1] = (part.astype(np.float64) ** 2).sum(axis=(0, 2, 3))
+    zt = nhwc_tensor(G, z, cop)
+    pd, gbd, rund = G.dev(partial), G.dev(gb), G.dev(run_in)
+    stats, coef = G.empty((2 * c,)), G.empty((capi.lib().unet_bn_coef_floats(cop),))
+    capi.unet_bn_finalize_bf16(G.p(pd), 2, c, cop, M, G.p(gbd), G.p(stats), G.p(rund), G.p(coef), None)
+    y = torch.full((n, h, w, cop + 8), 3.0, dtype=torch.bfloat16, device=G.DEV)   # y is a slice of a wider buffer
+    capi.unet_bn_act_bf16(G.p(zt), cop, y.data_ptr() + 16, cop + 8, G.p(coef), cop, n * h * w, act, None)
+    bn_ref, stats_ref, run_ref = oracle.bn_train(z, gb, run_in)
+    y_ref = [oracle.relu, oracle.sigmoid, lambda v: v][act](bn_ref)
+    yh = y.float().cpu().numpy()
+    assert np.all(yh[..., :8] == 3.0)
+    assert_close_bf16(yh[..., 8:8 + c].transpose(0, 3, 1, 2), y_ref, what=f"bn+act forward {cfg}")
+    assert_close(G.host(stats), stats_ref, rtol=1e-5, what="batch stats")
+    assert_close(G.host(rund), run_ref, rtol=1e-5, atol_scale=1e-6, what="running stats")
+
+    # backward: fan-in of two gradients, activation backward, BN backward, bias gradient
+    d1, d2 = nhwc_tensor(G, dy1, cop), nhwc_tensor(G, dy2, cop)
+    dz = torch.full((n, h, w, cop), float("nan"), dtype=torch.bfloat16, device=G.DEV)
+    ggb, gbias = G.empty((2 * c,)), G.empty((c,))
+    capi.unet_bn_act_backward_bf16(G.p(d1), cop, G.p(d2), cop, G.p(zt), cop, G.p(coef), G.p(gbd), G.p(dz), cop,
+                                   G.p(ggb), G.p(gbias), c, cop, n * h * w, act, None)
+    dy = dy1 + dy2
+    if act == 0:
+        g = oracle.relu_backward(dy, bn_ref)
+    elif act == 1:
+        g = oracle.sigmoid_backward(dy, oracle.sigmoid(bn_ref))
+    else:
+        g = dy
+    dz_ref, ggb_ref = oracle.bn_backward(z, g, gb, stats_ref)
+    got = nchw(dz, c)
+    assert_close_bf16(got, dz_ref, what=f"bn+act backward {cfg}")
+    gg = G.host(ggb)
+    assert np.abs(gg - ggb_ref).max() <= 2e-3 * np.abs(ggb_ref).max() + 1e-4, (gg, ggb_ref)
+    assert_close(G.host(gbias), got.astype(np.float64).sum(axis=(0, 2, 3)), rtol=1e-4, atol_scale=1e-4,
+                 what="bias gradient = sum of dz")
+    # single-source variant
+    capi.unet_bn_act_backward_bf16(G.p(d1), cop, None, 0, G.p(zt), cop, G.p(coef), G.p(gbd), G.p(dz), cop,
+                                   G.p(ggb), None, c, cop, n * h * w, act, None)
+    g1 = [lambda: oracle.relu_backward(dy1, bn_ref), lambda: oracle.sigmoid_backward(dy1, oracle.sigmoid(bn_ref)),
+          lambda: dy1][act]()
+    dz1_ref, _ = oracle.bn_backward(z, g1, gb, stats_ref)
+    assert_close_bf16(nchw(dz, c), dz1_ref, what=f"bn+act backward, one source {cfg}")
+
+
+def test_bn_inference_coef(G, capi, oracle):
+    n, c, h, w = 2, 32, 5, 6
+    rng = np.random.default_rng(2)
+    z = bf16_round(rng.standard_normal((n, c, h, w)))
+    gb = rng.standard_normal(2 * c).astype(np.float32)
+    run = np.abs(rng.standard_normal(2 * c)).astype(np.float32) + 0.1
+    zt, gbd, rund = nhwc_tensor(G, z), G.dev(gb), G.dev(run)
+    coef = G.empty((capi.lib().unet_bn_coef_floats(c),))
+    capi.unet_bn_inference_coef_bf16(G.p(gbd), G.p(rund), c, c, G.p(coef), None)
+    y = torch.empty((n, h, w, c), dtype=torch.bfloat16, device=G.DEV)
+    capi.unet_bn_act_bf16(G.p(zt), c, G.p(y), c, G.p(coef), c, n * h * w, 2, None)
+    assert_close_bf16(nchw(y, c), oracle.bn_inference(z, gb, run), what="bn inference bf16")
+
+
+@pytest.mark.parametrize("cfg", [(2, 64, 16, 16), (1, 32, 6, 10), (3, 8, 2, 2), (1, 128, 32, 32)])
+def test_max_pool_bf16(G, capi, oracle, cfg):
+    n, c, h, w = cfg
+    rng = np.random.default_rng(c + h)
+    x = bf16_round(np.maximum(np.round(rng.standard_normal((n, c, h, w)) * 4) / 4, 0))   # post-ReLU-like, many ties
+    dy = bf16_round(rng.standard_normal((n, c, h // 2, w // 2)))
+    xt, dyt = nhwc_tensor(G, x, c + 8), nhwc_tensor(G, dy)
+    y = torch.empty((n, h // 2, w // 2, c), dtype=torch.bfloat16, device=G.DEV)
+    mask = torch.full((n, h // 2, w // 2, c), 255, dtype=torch.uint8, device=G.DEV)
+    capi.unet_max_pool2x2_bf16(G.p(xt), c + 8, G.p(y), c, G.p(mask), n, h, w, c, None)
+    y_ref, tm_ref = oracle.maxpool(x, 2, 2, want_tiemask=True)
+    np.testing.assert_array_equal(nchw(y, c), y_ref)
+    np.testing.assert_array_equal(mask.cpu().numpy().transpose(0, 3, 1, 2), tm_ref)
+    dx = torch.full((n, h, w, c), float("nan"), dtype=torch.bfloat16, device=G.DEV)
+    capi.unet_max_pool2x2_backward_bf16(G.p(dyt), c, G.p(mask), G.p(dx), c, n, h, w, c, 0, None)
+    dx_ref = oracle.maxpool_backward(dy, x, y_ref, 2)
+    np.testing.assert_array_equal(nchw(dx, c), dx_ref)
+    capi.unet_max_pool2x2_backward_bf16(G.p(dyt), c, G.p(mask), G.p(dx), c, n, h, w, c, 1, None)
+    np.testing.assert_array_equal(nchw(dx, c), bf16_round(2 * dx_ref))

@@ -1,0 +1,499 @@
+// Bandwidth-bound kernels of the bf16 / NHWC path: batch-norm finalise,
+// fused BN + ReLU|Sigmoid apply, fused activation-backward + BN-backward (two
+// passes: reduce, apply), 2x2 max pool with a saved tie mask, and its backward.
+//
+// Every kernel moves 16 bytes (8 bf16 channels of one pixel) per lane; channel
+// reductions keep 8 channels' partial sums in registers per lane, combine the
+// lanes that share channels through LDS, write one partial per block, and a
+// tiny finalise kernel adds the partials in a fixed order (no atomics).
+#include "common.h"
+
+typedef uint16_t bf16_t;
+#define BN_EPS 1e-8f
+#define BN_MOMENTUM 0.9f
+
+namespace {
+
+__device__ __forceinline__ float bf2f(uint32_t h) { return __uint_as_float(h << 16); }
+__device__ __forceinline__ uint32_t f2bf(float f) {
+  __bf16 h = (__bf16)f;
+  return (uint32_t) __builtin_bit_cast(unsigned short, h);
+}
+__device__ __forceinline__ void unpack8(const uint4 &u, float (&v)[8]) {
+  const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    v[2 * j] = bf2f(w[j] & 0xffffu);
+    v[2 * j + 1] = bf2f(w[j] >> 16);
+  }
+}
+__device__ __forceinline__ uint4 pack8(const float (&v)[8]) {
+  uint32_t w[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) w[j] = f2bf(v[2 * j]) | (f2bf(v[2 * j + 1]) << 16);
+  return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+// Per-channel record produced by the forward finalise and consumed by the
+// apply / backward kernels.
+struct ChanFwd {
+  float a, b;        // y = act(a*z + b): a = gamma/(sqrt(var)+eps) [train] or gamma/sqrt(var+eps) [inference]
+  float mean, invb;  // batch mean and 1/sqrt(var+eps) (backward's x-hat)
+};
+struct ChanBwd {
+  float c0, k1, k2, pad;  // dz = c0*(g - k1 - xhat*k2): c0 = gamma*invb, k1 = dbeta/M, k2 = dgamma/M
+};
+
+// partials [P][CoP][2] (sum, sum of squares) -> batch_stats, running stats, ChanFwd
+__global__ void bn_finalize_fwd_kernel(const float *__restrict__ partials, int P, int C, int CoP, float M,
+                                       const float *__restrict__ gb, float *__restrict__ batch_stats,
+                                       float *__restrict__ running, ChanFwd *__restrict__ out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= CoP) return;
+  ChanFwd r{0.f, 0.f, 0.f, 0.f};
+  if (c < C) {
+    double s = 0, q = 0;
+    for (int p = 0; p < P; ++p) {
+      s += partials[((i64)p * CoP + c) * 2];
+      q += partials[((i64)p * CoP + c) * 2 + 1];
+    }
+    const float mean = (float)(s / M);
+    float var = (float)(q / M - (s / M) * (s / M));
+    var = var < 0.f ? 0.f : var;
+    batch_stats[2 * c] = (float)s;
+    batch_stats[2 * c + 1] = (float)q;
+    if (running) {
+      running[2 * c] = running[2 * c] * BN_MOMENTUM + (1.0f - BN_MOMENTUM) * mean;
+      running[2 * c + 1] = running[2 * c + 1] * BN_MOMENTUM + (1.0f - BN_MOMENTUM) * var;
+    }
+    r.a = gb[2 * c] / (sqrtf(var) + BN_EPS);
+    r.b = gb[2 * c + 1] - r.a * mean;
+    r.mean = mean;
+    r.invb = 1.0f / sqrtf(var + BN_EPS);
+  }
+  out[c] = r;
+}
+
+// inference: a, b from the running statistics
+__global__ void bn_inference_coef_kernel(const float *__restrict__ gb, const float *__restrict__ running, int C,
+                                         int CoP, ChanFwd *__restrict__ out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= CoP) return;
+  ChanFwd r{0.f, 0.f, 0.f, 0.f};
+  if (c < C) {
+    r.invb = 1.0f / sqrtf(running[2 * c + 1] + BN_EPS);
+    r.a = gb[2 * c] * r.invb;
+    r.mean = running[2 * c];
+    r.b = gb[2 * c + 1] - r.a * r.mean;
+  }
+  out[c] = r;
+}
+
+// y = act(a*z + b), 8 channels per lane.  ACT: 0 ReLU, 1 sigmoid, 2 identity.
+// A lane keeps its channel group for all of its pixels, so the 16 coefficients
+// live in registers.
+template <int ACT>
+__global__ __launch_bounds__(256) void bn_act_kernel(const bf16_t *__restrict__ z, int z_ld, bf16_t *__restrict__ y,
+                                                     int y_ld, const ChanFwd *__restrict__ cf, int CG, int PL,
+                                                     i64 pixels) {
+  const int cg = threadIdx.x % CG, pl = threadIdx.x / CG;
+  if (pl >= PL) return;
+  float ca[8], cb[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const ChanFwd c = cf[cg * 8 + j];
+    ca[j] = c.a;
+    cb[j] = c.b;
+  }
+  for (i64 p = (i64)blockIdx.x * PL + pl; p < pixels; p += (i64)gridDim.x * PL) {
+    float v[8];
+    unpack8(*reinterpret_cast<const uint4 *>(z + p * z_ld + cg * 8), v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float t = fmaf(ca[j], v[j], cb[j]);
+      if (ACT == 0) t = t > 0.f ? t : 0.f;
+      if (ACT == 1) t = 1.0f / (1.0f + __expf(-t));
+      v[j] = t;
+    }
+    *reinterpret_cast<uint4 *>(y + p * y_ld + cg * 8) = pack8(v);
+  }
+}
+
+// ---- backward -------------------------------------------------------------------
+// g = (dy1 + dy2) * act'(.)   with act' from the recomputed BN output a*z + b
+template <int ACT>
+__device__ __forceinline__ float act_grad(float dy, float t) {
+  if (ACT == 0) return t > 0.f ? dy : 0.f;
+  if (ACT == 1) {
+    const float s = 1.0f / (1.0f + __expf(-t));
+    return dy * s * (1.0f - s);
+  }
+  return dy;
+}
+
+// pass 1: partial[b][c][2] = (sum g*xhat, sum g) over block b's pixels
+template <int ACT>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const bf16_t *__restrict__ dy1, int ld1,
+                                                            const bf16_t *__restrict__ dy2, int ld2,
+                                                            const bf16_t *__restrict__ z, int z_ld,
+                                                            const ChanFwd *__restrict__ cf, int CG, int PL,
+                                                            i64 pixels, i64 ppb, float *__restrict__ partial,
+                                                            int CoP) {
+  extern __shared__ float red[];  // [PL][CG*16]
+  const int tid = threadIdx.x;
+  const int cg = tid % CG, pl = tid / CG;
+  const bool active = pl < PL;
+  float s[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) s[j] = 0.f;
+  if (active) {
+    ChanFwd c[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) c[j] = cf[cg * 8 + j];
+    const i64 p0 = (i64)blockIdx.x * ppb, p1 = min(pixels, p0 + ppb);
+    for (i64 p = p0 + pl; p < p1; p += PL) {
+      float g[8], zv[8];
+      unpack8(*reinterpret_cast<const uint4 *>(dy1 + p * ld1 + cg * 8), g);
+      if (dy2) {
+        float g2[8];
+        unpack8(*reinterpret_cast<const uint4 *>(dy2 + p * ld2 + cg * 8), g2);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) g[j] += g2[j];
+      }
+      unpack8(*reinterpret_cast<const uint4 *>(z + p * z_ld + cg * 8), zv);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float gj = act_grad<ACT>(g[j], fmaf(c[j].a, zv[j], c[j].b));
+        s[2 * j] += gj * ((zv[j] - c[j].mean) * c[j].invb);
+        s[2 * j + 1] += gj;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) red[(pl * CG + cg) * 16 + j] = s[j];
+  }
+  __syncthreads();
+  // thread t < CG*16 sums column t over the PL pixel lanes
+  for (int t = tid; t < CG * 16; t += 256) {
+    float acc = 0.f;
+    for (int l = 0; l < PL; ++l) acc += red[l * CG * 16 + t];
+    // t = cg*16 + 2*j + which  ->  channel cg*8 + j
+    const int ch = (t >> 4) * 8 + ((t & 15) >> 1);
+    partial[((i64)blockIdx.x * CoP + ch) * 2 + (t & 1)] = acc;
+  }
+}
+
+// sums partials; writes grad_gb[2c] = dgamma, [2c+1] = dbeta and the ChanBwd record
+__global__ void bn_finalize_bwd_kernel(const float *__restrict__ partials, int P, int C, int CoP, float M,
+                                       const float *__restrict__ gb, const ChanFwd *__restrict__ cf,
+                                       float *__restrict__ grad_gb, ChanBwd *__restrict__ out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= CoP) return;
+  ChanBwd r{0.f, 0.f, 0.f, 0.f};
+  if (c < C) {
+    double dg = 0, db = 0;
+    for (int p = 0; p < P; ++p) {
+      dg += partials[((i64)p * CoP + c) * 2];
+      db += partials[((i64)p * CoP + c) * 2 + 1];
+    }
+    grad_gb[2 * c] = (float)dg;
+    grad_gb[2 * c + 1] = (float)db;
+    r.c0 = gb[2 * c] * cf[c].invb;
+    r.k1 = (float)(db / M);
+    r.k2 = (float)(dg / M);
+  }
+  out[c] = r;
+}
+
+// pass 2: dz = c0*(g - k1 - xhat*k2) (bf16) and per-block sums of dz (bias gradient)
+template <int ACT>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16_t *__restrict__ dy1, int ld1,
+                                                           const bf16_t *__restrict__ dy2, int ld2,
+                                                           const bf16_t *__restrict__ z, int z_ld,
+                                                           const ChanFwd *__restrict__ cf,
+                                                           const ChanBwd *__restrict__ cb, bf16_t *__restrict__ dz,
+                                                           int dz_ld, int CG, int PL, i64 pixels, i64 ppb,
+                                                           float *__restrict__ partial, int CoP) {
+  extern __shared__ float red[];  // [PL][CG*8]
+  const int tid = threadIdx.x;
+  const int cg = tid % CG, pl = tid / CG;
+  const bool active = pl < PL;
+  float s[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) s[j] = 0.f;
+  if (active) {
+    ChanFwd c[8];
+    ChanBwd b[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      c[j] = cf[cg * 8 + j];
+      b[j] = cb[cg * 8 + j];
+    }
+    const i64 p0 = (i64)blockIdx.x * ppb, p1 = min(pixels, p0 + ppb);
+    for (i64 p = p0 + pl; p < p1; p += PL) {
+      float g[8], zv[8], o[8];
+      unpack8(*reinterpret_cast<const uint4 *>(dy1 + p * ld1 + cg * 8), g);
+      if (dy2) {
+        float g2[8];
+        unpack8(*reinterpret_cast<const uint4 *>(dy2 + p * ld2 + cg * 8), g2);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) g[j] += g2[j];
+      }
+      unpack8(*reinterpret_cast<const uint4 *>(z + p * z_ld + cg * 8), zv);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float gj = act_grad<ACT>(g[j], fmaf(c[j].a, zv[j], c[j].b));
+        const float xh = (zv[j] - c[j].mean) * c[j].invb;
+        o[j] = b[j].c0 * (gj - b[j].k1 - xh * b[j].k2);
+      }
+      const uint4 packed = pack8(o);
+      *reinterpret_cast<uint4 *>(dz + p * dz_ld + cg * 8) = packed;
+      float r[8];
+      unpack8(packed, r);  // the bias gradient sums what the weight-gradient kernels will read
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s[j] += r[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[(pl * CG + cg) * 8 + j] = s[j];
+  }
+  __syncthreads();
+  for (int t = tid; t < CG * 8; t += 256) {
+    float acc = 0.f;
+    for (int l = 0; l < PL; ++l) acc += red[l * CG * 8 + t];
+    partial[(i64)blockIdx.x * CoP + t] = acc;
+  }
+}
+
+// out[c] = sum_p partial[p][c], c < C
+__global__ void column_sum_kernel(const float *__restrict__ partial, int P, int C, int stride,
+                                  float *__restrict__ out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0;
+  for (int p = 0; p < P; ++p) s += partial[(i64)p * stride + c];
+  out[c] = (float)s;
+}
+
+// ---- 2x2 / stride 2 max pool -------------------------------------------------------
+// mask[n,ho,wo,c] bit (2*i+j) set when x[n,2ho+i,2wo+j,c] equals the maximum
+// (every tied maximum, the reference's backward rule; the lowest set bit is the
+// first maximum in row-major order).
+__global__ __launch_bounds__(256) void maxpool2_kernel(const bf16_t *__restrict__ x, int x_ld,
+                                                       bf16_t *__restrict__ y, int y_ld,
+                                                       uint8_t *__restrict__ mask, int CG, int H, int W, i64 total) {
+  const int Ho = H / 2, Wo = W / 2;
+  for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (i64)gridDim.x * blockDim.x) {
+    const int cg = (int)(i % CG);
+    i64 t = i / CG;
+    const int wo = (int)(t % Wo);
+    t /= Wo;
+    const int ho = (int)(t % Ho);
+    const i64 n = t / Ho;
+    const bf16_t *xp = x + ((n * H + 2 * ho) * W + 2 * wo) * (i64)x_ld + cg * 8;
+    float v[4][8];
+    unpack8(*reinterpret_cast<const uint4 *>(xp), v[0]);
+    unpack8(*reinterpret_cast<const uint4 *>(xp + x_ld), v[1]);
+    unpack8(*reinterpret_cast<const uint4 *>(xp + (i64)W * x_ld), v[2]);
+    unpack8(*reinterpret_cast<const uint4 *>(xp + (i64)W * x_ld + x_ld), v[3]);
+    float m[8];
+    uint32_t mk[2] = {0, 0};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      m[j] = fmaxf(fmaxf(v[0][j], v[1][j]), fmaxf(v[2][j], v[3][j]));
+      uint32_t bits = 0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) bits |= (v[k][j] == m[j]) ? (1u << k) : 0u;
+      mk[j >> 2] |= bits << (8 * (j & 3));
+    }
+    const i64 o = ((n * Ho + ho) * Wo + wo);
+    *reinterpret_cast<uint4 *>(y + o * y_ld + cg * 8) = pack8(m);
+    *reinterpret_cast<uint2 *>(mask + o * (CG * 8) + cg * 8) = make_uint2(mk[0], mk[1]);
+  }
+}
+
+__global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const bf16_t *__restrict__ dy, int dy_ld,
+                                                           const uint8_t *__restrict__ mask,
+                                                           bf16_t *__restrict__ dx, int dx_ld, int CG, int H, int W,
+                                                           i64 total, int accumulate) {
+  const int Ho = H / 2, Wo = W / 2;
+  for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (i64)gridDim.x * blockDim.x) {
+    const int cg = (int)(i % CG);
+    i64 t = i / CG;
+    const int wo = (int)(t % Wo);
+    t /= Wo;
+    const int ho = (int)(t % Ho);
+    const i64 n = t / Ho;
+    const i64 o = ((n * Ho + ho) * Wo + wo);
+    float g[8];
+    unpack8(*reinterpret_cast<const uint4 *>(dy + o * dy_ld + cg * 8), g);
+    const uint2 mk = *reinterpret_cast<const uint2 *>(mask + o * (CG * 8) + cg * 8);
+    bf16_t *xp = dx + ((n * H + 2 * ho) * W + 2 * wo) * (i64)dx_ld + cg * 8;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      bf16_t *dst = xp + (i64)(k >> 1) * W * dx_ld + (k & 1) * dx_ld;
+      float r[8];
+      if (accumulate)
+        unpack8(*reinterpret_cast<const uint4 *>(dst), r);
+      else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] = 0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const uint32_t bits = ((j < 4 ? mk.x : mk.y) >> (8 * (j & 3))) & 0xffu;
+        if (bits & (1u << k)) r[j] += g[j];
+      }
+      *reinterpret_cast<uint4 *>(dst) = pack8(r);
+    }
+  }
+}
+
+struct RedPlan {
+  int CG, PL, blocks;
+  i64 ppb;
+};
+RedPlan plan_reduce(int CoP, i64 pixels) {
+  RedPlan r;
+  r.CG = CoP / 8;
+  r.PL = 256 / r.CG;
+  i64 b = (pixels + (i64)r.PL * 8 - 1) / ((i64)r.PL * 8);
+  if (b > 1024) b = 1024;
+  if (b < 1) b = 1;
+  r.ppb = (pixels + b - 1) / b;
+  r.blocks = (int)((pixels + r.ppb - 1) / r.ppb);
+  return r;
+}
+
+int check_view(const char *name, const void *p, int ld, int CoP) {
+  UNET_REQUIRE(p, "%s: NULL pointer", name);
+  UNET_REQUIRE(ld >= CoP && ld % 8 == 0 && (((uintptr_t)p) & 15) == 0,
+               "%s: pixel stride must be a multiple of 8 and >= the channel count, pointer 16-byte aligned", name);
+  return UNET_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int unet_bn_coef_floats(int CoP) { return 4 * CoP; }
+
+int unet_bn_finalize_bf16(const float *stat_partials, int num_partials, int C, int CoP, int64_t count,
+                          const float *gamma_beta, float *batch_stats, float *running_stats, float *coef,
+                          unet_stream_t s) {
+  UNET_REQUIRE(stat_partials && gamma_beta && batch_stats && coef, "unet_bn_finalize_bf16: NULL pointer");
+  UNET_REQUIRE(num_partials > 0 && C > 0 && CoP >= C && count > 0, "unet_bn_finalize_bf16: bad sizes");
+  hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(cdiv_u(CoP, 64)), dim3(64), 0, as_stream(s), stat_partials,
+                     num_partials, C, CoP, (float)count, gamma_beta, batch_stats, running_stats,
+                     reinterpret_cast<ChanFwd *>(coef));
+  UNET_LAUNCH_CHECK("bn_finalize_fwd_kernel");
+  return UNET_OK;
+}
+
+int unet_bn_inference_coef_bf16(const float *gamma_beta, const float *running_stats, int C, int CoP, float *coef,
+                                unet_stream_t s) {
+  UNET_REQUIRE(gamma_beta && running_stats && coef && C > 0 && CoP >= C, "unet_bn_inference_coef_bf16: bad argument");
+  hipLaunchKernelGGL(bn_inference_coef_kernel, dim3(cdiv_u(CoP, 64)), dim3(64), 0, as_stream(s), gamma_beta,
+                     running_stats, C, CoP, reinterpret_cast<ChanFwd *>(coef));
+  UNET_LAUNCH_CHECK("bn_inference_coef_kernel");
+  return UNET_OK;
+}
+
+int unet_bn_act_bf16(const uint16_t *z, int z_ld, uint16_t *y, int y_ld, const float *coef, int CoP,
+                     int64_t pixels, int act, unet_stream_t s) {
+  int rc = check_view("unet_bn_act_bf16 (z)", z, z_ld, CoP);
+  if (!rc) rc = check_view("unet_bn_act_bf16 (y)", y, y_ld, CoP);
+  if (rc) return rc;
+  UNET_REQUIRE(coef && CoP > 0 && CoP % 8 == 0 && CoP <= 2048 && pixels > 0 && act >= 0 && act <= 2,
+               "unet_bn_act_bf16: bad argument (CoP must be a multiple of 8, at most 2048)");
+  const int CG = CoP / 8, PL = 256 / CG;
+  const dim3 grid(ew_grid((pixels + PL - 1) / PL * 256 / 4));
+  const ChanFwd *cf = reinterpret_cast<const ChanFwd *>(coef);
+  ProfScope prof(PROF_BN_RELU_BF16, 0, 4.0 * pixels * CoP, as_stream(s));
+  if (act == 0)
+    hipLaunchKernelGGL(bn_act_kernel<0>, grid, dim3(256), 0, as_stream(s), z, z_ld, y, y_ld, cf, CG, PL, (i64)pixels);
+  else if (act == 1)
+    hipLaunchKernelGGL(bn_act_kernel<1>, grid, dim3(256), 0, as_stream(s), z, z_ld, y, y_ld, cf, CG, PL, (i64)pixels);
+  else
+    hipLaunchKernelGGL(bn_act_kernel<2>, grid, dim3(256), 0, as_stream(s), z, z_ld, y, y_ld, cf, CG, PL, (i64)pixels);
+  UNET_LAUNCH_CHECK("bn_act_kernel");
+  return UNET_OK;
+}
+
+int unet_bn_act_backward_bf16(const uint16_t *dy1, int ld1, const uint16_t *dy2, int ld2, const uint16_t *z, int z_ld,
+                              const float *coef, const float *gamma_beta, uint16_t *dz, int dz_ld, float *grad_gb,
+                              float *grad_bias, int C, int CoP, int64_t pixels, int act, unet_stream_t s) {
+  int rc = check_view("unet_bn_act_backward_bf16 (dy1)", dy1, ld1, CoP);
+  if (!rc && dy2) rc = check_view("unet_bn_act_backward_bf16 (dy2)", dy2, ld2, CoP);
+  if (!rc) rc = check_view("unet_bn_act_backward_bf16 (z)", z, z_ld, CoP);
+  if (!rc) rc = check_view("unet_bn_act_backward_bf16 (dz)", dz, dz_ld, CoP);
+  if (rc) return rc;
+  UNET_REQUIRE(coef && gamma_beta && grad_gb && C > 0 && CoP >= C && CoP % 8 == 0 && CoP <= 2048 && pixels > 0 &&
+                   act >= 0 && act <= 2,
+               "unet_bn_act_backward_bf16: bad argument (CoP must be a multiple of 8, at most 2048)");
+  const RedPlan pl = plan_reduce(CoP, pixels);
+  // workspace: partials [blocks][CoP][2] | ChanBwd [CoP] | bias partials [blocks][CoP]
+  const size_t n_part = (size_t)pl.blocks * CoP * 2, n_cb = (size_t)CoP * 4, n_bias = (size_t)pl.blocks * CoP;
+  void *ws;
+  rc = unet_workspace(&ws, sizeof(float) * (n_part + n_cb + n_bias));
+  if (rc) return rc;
+  float *partial = (float *)ws, *cbf = partial + n_part, *bias_part = cbf + n_cb;
+  const ChanFwd *cf = reinterpret_cast<const ChanFwd *>(coef);
+  ChanBwd *cb = reinterpret_cast<ChanBwd *>(cbf);
+  const size_t lds1 = sizeof(float) * (size_t)pl.PL * pl.CG * 16, lds2 = sizeof(float) * (size_t)pl.PL * pl.CG * 8;
+  ProfScope prof(PROF_BN_RELU_BF16, 0, 2.0 * pixels * CoP * (dy2 ? 7.0 : 5.0), as_stream(s));
+#define BWD_LAUNCH(ACT_)                                                                                            \
+  do {                                                                                                              \
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel<ACT_>, dim3(pl.blocks), dim3(256), lds1, as_stream(s), dy1, ld1, dy2,  \
+                       ld2, z, z_ld, cf, pl.CG, pl.PL, (i64)pixels, pl.ppb, partial, CoP);                          \
+    UNET_LAUNCH_CHECK("bn_bwd_reduce_kernel");                                                                      \
+    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(cdiv_u(CoP, 64)), dim3(64), 0, as_stream(s),                    \
+                       (const float *)partial, pl.blocks, C, CoP, (float)pixels, gamma_beta, cf, grad_gb, cb);      \
+    UNET_LAUNCH_CHECK("bn_finalize_bwd_kernel");                                                                    \
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<ACT_>, dim3(pl.blocks), dim3(256), lds2, as_stream(s), dy1, ld1, dy2,   \
+                       ld2, z, z_ld, cf, (const ChanBwd *)cb, dz, dz_ld, pl.CG, pl.PL, (i64)pixels, pl.ppb,         \
+                       bias_part, CoP);                                                                             \
+    UNET_LAUNCH_CHECK("bn_bwd_apply_kernel");                                                                       \
+  } while (0)
+  if (act == 0) BWD_LAUNCH(0);
+  else if (act == 1) BWD_LAUNCH(1);
+  else BWD_LAUNCH(2);
+#undef BWD_LAUNCH
+  if (grad_bias) {
+    hipLaunchKernelGGL(column_sum_kernel, dim3(cdiv_u(C, 64)), dim3(64), 0, as_stream(s), (const float *)bias_part,
+                       pl.blocks, C, CoP, grad_bias);
+    UNET_LAUNCH_CHECK("column_sum_kernel");
+  }
+  return UNET_OK;
+}
+
+int unet_max_pool2x2_bf16(const uint16_t *x, int x_ld, uint16_t *y, int y_ld, uint8_t *mask, int N, int H, int W,
+                          int C, unet_stream_t s) {
+  int rc = check_view("unet_max_pool2x2_bf16 (x)", x, x_ld, C);
+  if (!rc) rc = check_view("unet_max_pool2x2_bf16 (y)", y, y_ld, C);
+  if (rc) return rc;
+  UNET_REQUIRE(mask && N > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && C > 0 && C % 8 == 0 &&
+                   (((uintptr_t)mask) & 7) == 0,
+               "unet_max_pool2x2_bf16: need even H and W, channels a multiple of 8, an 8-byte aligned mask");
+  const i64 total = (i64)N * (H / 2) * (W / 2) * (C / 8);
+  ProfScope prof(PROF_POOL_BF16, 0, (double)N * H * W * C * 2.0 * 1.25 + (double)total * 8, as_stream(s));
+  hipLaunchKernelGGL(maxpool2_kernel, dim3(ew_grid(total)), dim3(256), 0, as_stream(s), x, x_ld, y, y_ld, mask, C / 8,
+                     H, W, total);
+  UNET_LAUNCH_CHECK("maxpool2_kernel");
+  return UNET_OK;
+}
+
+int unet_max_pool2x2_backward_bf16(const uint16_t *dy, int dy_ld, const uint8_t *mask, uint16_t *dx, int dx_ld, int N,
+                                   int H, int W, int C, int accumulate, unet_stream_t s) {
+  int rc = check_view("unet_max_pool2x2_backward_bf16 (dy)", dy, dy_ld, C);
+  if (!rc) rc = check_view("unet_max_pool2x2_backward_bf16 (dx)", dx, dx_ld, C);
+  if (rc) return rc;
+  UNET_REQUIRE(mask && N > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && C > 0 && C % 8 == 0,
+               "unet_max_pool2x2_backward_bf16: need even H and W and channels a multiple of 8");
+  const i64 total = (i64)N * (H / 2) * (W / 2) * (C / 8);
+  ProfScope prof(PROF_POOL_BF16, 0, (double)N * H * W * C * 2.0 * 1.25 + (double)total * 8, as_stream(s));
+  hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(ew_grid(total)), dim3(256), 0, as_stream(s), dy, dy_ld, mask, dx, dx_ld,
+                     C / 8, H, W, total, accumulate);
+  UNET_LAUNCH_CHECK("maxpool2_bwd_kernel");
+  return UNET_OK;
+}
+
+}  // extern "C"
