@@ -130,27 +130,88 @@ def flat_grads(graph, params):
     return torch.cat(parts).numpy()
 
 
-def forward(graph, params, x, training=True, running=None):
+class _RoundBF16(torch.autograd.Function):
+    """Rounds to bf16 in forward AND rounds the gradient to bf16 in backward:
+    models a tensor (and its gradient) that is stored in bf16."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.to(torch.bfloat16).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16).to(g.dtype)
+
+
+class _RoundBF16Value(torch.autograd.Function):
+    """Rounds to bf16 in forward, passes the gradient through unchanged: models
+    bf16 copies of fp32 master weights."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.to(torch.bfloat16).to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+class _MaxPoolTies(torch.autograd.Function):
+    """k x k / stride k max pool whose backward gives the gradient to EVERY
+    element equal to the window maximum (the reference's rule,
+    src/cuda_library/max_pool/max_pool.cu:172), not just the first."""
+
+    @staticmethod
+    def forward(ctx, x, k):
+        y = F.max_pool2d(x, k, k)
+        ctx.save_for_backward(x, y)
+        ctx.k = k
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, y = ctx.saved_tensors
+        k = ctx.k
+        up = lambda t: t.repeat_interleave(k, 2).repeat_interleave(k, 3)
+        return (x == up(y)).to(g.dtype) * up(g), None
+
+
+def forward(graph, params, x, training=True, running=None, emulate_bf16=False):
     """x float64 [N,C,H,W] -> list of per-layer activations.  `running`
     (optional list of [mean,var] interleaved arrays per layer) is used when
-    training=False."""
+    training=False.
+
+    emulate_bf16=True restates the module's bf16 path: the input, the weights
+    (values only), every convolution output and every activation are rounded
+    to bf16 where the module stores them in bf16, gradients are rounded where
+    the module stores them in bf16, batch-norm statistics are taken from the
+    rounded convolution output, the final (narrow) layer's batch norm,
+    activation and loss stay in full precision, and max pool routes gradients
+    to every tied maximum.  Arithmetic stays float64."""
+    rnd = _RoundBF16.apply if emulate_bf16 else (lambda t: t)
+    rndw = _RoundBF16Value.apply if emulate_bf16 else (lambda t: t)
+    if emulate_bf16:
+        x = x.to(torch.bfloat16).to(x.dtype)
     acts = []
+    last = len(graph) - 1
     for i, (kind, s, parents, act) in enumerate(graph):
         inp = x if not parents else acts[parents[0]]
         if kind in ("conv", "up"):
             p = params[i]
             if kind == "conv":
-                z = F.conv2d(inp, p["w"].permute(1, 0, 2, 3), p["b"], stride=s[6], padding=s[5])
+                z = F.conv2d(inp, rndw(p["w"]).permute(1, 0, 2, 3), p["b"], stride=s[6], padding=s[5])
             else:
-                z = F.conv_transpose2d(inp, p["w"], p["b"], stride=s[4])
+                z = F.conv_transpose2d(inp, rndw(p["w"]), p["b"], stride=s[4])
+            z = rnd(z)
             if training:
                 y = F.batch_norm(z, None, None, p["gamma"], p["beta"], training=True, eps=BN_EPS)
             else:
                 r = torch.as_tensor(np.asarray(running[i], dtype=np.float64))
                 y = F.batch_norm(z, r[0::2], r[1::2], p["gamma"], p["beta"], training=False, eps=BN_EPS)
-            acts.append(torch.sigmoid(y) if act == "sigmoid" else torch.relu(y))
+            y = torch.sigmoid(y) if act == "sigmoid" else torch.relu(y)
+            acts.append(y if i == last else rnd(y))
         elif kind == "pool":
-            acts.append(F.max_pool2d(inp, s[3], s[4]))
+            acts.append(_MaxPoolTies.apply(inp, s[3]) if emulate_bf16 else F.max_pool2d(inp, s[3], s[4]))
         elif kind == "concat":
             acts.append(torch.cat([acts[parents[0]], acts[parents[1]]], dim=1))
         else:

@@ -50,6 +50,32 @@ def assert_close_bf16(a, ref, what=""):
             f"worst at {i}: got {a[i]!r} want {ref[i]!r} (rms {rms:.3g})")
 
 
+def assert_close_bf16_net(a, ref, what="", rel_bar=None, guard=True):
+    """Activations / gradients that passed through several bf16 layers: each
+    layer adds rounding noise of ~0.5 % of the tensor's rms (bf16 keeps 8
+    significant bits; a 3x3 convolution sums hundreds of rounded products), so
+    the bound is on the relative L2 error (<= 2e-2) with a per-element guard of
+    2e-2*|x| + 0.15*rms against outliers (the tail of the accumulated rounding noise
+    reaches several sigma among ~1e5 elements)."""
+    a = np.asarray(a, dtype=np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    assert a.shape == ref.shape, f"{what}: shape {a.shape} vs {ref.shape}"
+    assert np.isfinite(a).all(), f"{what}: non-finite values in result"
+    rms = float(np.sqrt(np.mean(ref * ref))) if ref.size else 0.0
+    rel = float(np.linalg.norm(a - ref) / max(np.linalg.norm(ref), 1e-30))
+    rel_bar = BF16_RTOL if rel_bar is None else rel_bar
+    assert rel <= rel_bar, f"{what}: relative L2 error {rel:.3g} > {rel_bar:.3g}"
+    if not guard:
+        return
+    err = np.abs(a - ref)
+    bound = BF16_RTOL * np.maximum(np.abs(a), np.abs(ref)) + 0.15 * rms
+    bad = err > bound
+    if bad.any():
+        i = np.unravel_index(np.argmax(err - bound), err.shape)
+        raise AssertionError(f"{what}: {int(bad.sum())}/{a.size} elements outside the per-element guard; "
+                             f"worst at {i}: got {a[i]!r} want {ref[i]!r} (rms {rms:.3g})")
+
+
 def assert_exact(a, ref, what=""):
     a = np.asarray(a)
     ref = np.asarray(ref)

@@ -215,6 +215,7 @@ class NN {
     return out;
   }
   float last_epoch_loss() const { return last_epoch_loss_; }
+  std::string compute_dtype() const { return net_.is_bf16() ? "bf16" : "f32"; }
 
  private:
   void check_input(int64_t C, int64_t H, int64_t W) {
@@ -355,7 +356,8 @@ PYBIND11_MODULE(neural_net, m) {
       .def("synchronize", &NN::synchronize)
       .def("set_bucket_bytes", &NN::set_bucket_bytes)
       .def("gradient_buckets", &NN::gradient_buckets)
-      .def("last_epoch_loss", &NN::last_epoch_loss);
+      .def("last_epoch_loss", &NN::last_epoch_loss)
+      .def("compute_dtype", &NN::compute_dtype);
 
   py::class_<Convolution>(m, "Convolution")
       .def(py::init<>())

@@ -77,6 +77,8 @@ class DeviceBuffer {
     bytes_ = 0;
   }
   float *f32() const { return static_cast<float *>(ptr_); }
+  uint16_t *u16() const { return static_cast<uint16_t *>(ptr_); }
+  uint8_t *u8() const { return static_cast<uint8_t *>(ptr_); }
   void *raw() const { return ptr_; }
   size_t bytes() const { return bytes_; }
 
@@ -106,6 +108,23 @@ struct Node {
   DeviceBuffer z, bn, act;
   DeviceBuffer grad_out;  // dL/d(act)
   bool grad_seen = false;
+  // ---- bf16 / NHWC path ----
+  int cip = 0, cop = 0;          // channel counts padded to multiples of 32
+  bool narrow = false;           // final layer with C_out not a multiple of 32: BN/activation/loss run in fp32
+  DeviceBuffer zb;               // conv / tconv output before BN, [N,H,W,cop] bf16
+  DeviceBuffer yb;               // activation, when it is not a slice of a concat buffer
+  uint16_t *y_ptr = nullptr;     // where the activation lives ...
+  int y_ld = 0;                  // ... and its pixel stride
+  DeviceBuffer gb;               // gradient w.r.t. the activation from non-concat consumers, [N,H,W,ld] bf16
+  bool g_written = false;
+  const uint16_t *g2_ptr = nullptr;  // second gradient source: this layer's slice of a concat's gradient
+  int g2_ld = 0;
+  DeviceBuffer mask;             // max pool tie mask
+  DeviceBuffer coef;             // batch-norm coefficients of the last forward
+  DeviceBuffer w_fwd, w_bwd;     // packed bf16 weights
+  DeviceBuffer stat_partials;
+  int concat_child = -1;         // index of the CONCAT consumer (at most one on this path)
+  int concat_slot = 0;           // 0: first parent (skip), 1: second parent
   int64_t in_elems() const { return (int64_t)in_c * in_h * in_w; }
   int64_t out_elems() const { return (int64_t)out_c * out_h * out_w; }
   bool has_params() const { return type == CONV_LAYER || type == UPSAMPLING_LAYER; }
@@ -176,7 +195,15 @@ class Net {
     if (verbose_)
       for (const Node &n : nodes_)
         if (n.has_params()) std::cout << "add params: " << n.num_wb + n.num_bn << std::endl;
+    // compute path: bf16 NHWC on the matrix cores when the graph allows it
+    const char *want = std::getenv("UNET_DTYPE");
+    const bool want_bf16 = !want || std::string(want) != "fp32";
+    std::string why;
+    use_bf16_ = want_bf16 && plan_bf16(why);
+    if (want_bf16 && !use_bf16_ && verbose_)
+      std::cout << "note: using the fp32 kernels (" << why << ")" << std::endl;
   }
+  bool is_bf16() const { return use_bf16_; }
 
   // He(fan-in) weights, zero biases, gamma = 1, beta = 0, running mean 0 /
   // var 1.  (The reference's BN initialiser never runs, leaving gamma = 0:
@@ -208,6 +235,12 @@ class Net {
     if (batch < 1) throw std::runtime_error("Batch size must be greater than 0");
     require_created();
     ensure_batch(batch);
+    if (use_bf16_) {
+      if (params_dirty_) pack_all_weights();
+      UNET_CALL(unet_nchw_f32_to_nhwc_bf16(images, x16_.u16(), batch, in_c_, in_h_, in_w_, 32, 32, stream_));
+      for (Node &n : nodes_) forward_node_bf16(n, batch, inference);
+      return;
+    }
     for (Node &n : nodes_) forward_node(n, images, batch, inference);
   }
 
@@ -234,8 +267,16 @@ class Net {
                                                   (int64_t)batch * f.out_h * f.out_w, stream_));
     }
     f.grad_seen = true;
+    if (use_bf16_)
+      for (Node &n : nodes_) {
+        n.g_written = false;
+        n.g2_ptr = nullptr;
+      }
     for (int i = (int)nodes_.size() - 1; i >= 0; --i) {
-      backward_node(nodes_[i], images, batch);
+      if (use_bf16_)
+        backward_node_bf16(nodes_[i], batch);
+      else
+        backward_node(nodes_[i], images, batch);
       record_finished_buckets(i);
     }
   }
@@ -303,8 +344,14 @@ class Net {
     UNET_CALL(unet_memcpy_d2h(dst, grads_.raw(), sizeof(float) * (size_t)total_params_, 1, stream_));
   }
   void copy_output_to_host(int layer, float *dst, int batch) {
-    const Node &n = nodes_.at(layer);
-    UNET_CALL(unet_memcpy_d2h(dst, n.act.raw(), sizeof(float) * (size_t)batch * n.out_elems(), 1, stream_));
+    Node &n = nodes_.at(layer);
+    const size_t bytes = sizeof(float) * (size_t)batch * n.out_elems();
+    if (use_bf16_ && !n.narrow) {
+      // NHWC bf16 (possibly a slice of a concat buffer) -> NCHW fp32
+      n.act.ensure(bytes);
+      UNET_CALL(unet_nhwc_bf16_to_nchw_f32(n.y_ptr, n.act.f32(), batch, n.out_c, n.out_h, n.out_w, n.y_ld, stream_));
+    }
+    UNET_CALL(unet_memcpy_d2h(dst, n.act.raw(), bytes, 1, stream_));
   }
   void copy_running_stats_to_host(int layer, float *dst) {
     const Node &n = nodes_.at(layer);
@@ -371,6 +418,11 @@ class Net {
     if (batch <= alloc_batch_) return;
     const size_t b = (size_t)batch;
     int64_t max_out = 0, max_in = 0;
+    if (use_bf16_) {
+      ensure_batch_bf16(batch);
+      alloc_batch_ = batch;
+      return;
+    }
     for (Node &n : nodes_) {
       const size_t out_bytes = sizeof(float) * b * (size_t)n.out_elems();
       if (n.has_params()) {
@@ -646,6 +698,260 @@ class Net {
     }
   }
 
+  // ======================= bf16 / NHWC compute path ============================
+  static int pad32(int c) { return (c + 31) / 32 * 32; }
+
+  // Decides whether the graph can run on the bf16 kernels and, if so, lays out
+  // the activations: a layer feeding a CONCAT writes straight into its slice of
+  // the concat buffer, so concat forward and backward move no data.
+  bool plan_bf16(std::string &why) {
+    for (Node &n : nodes_) {
+      n.concat_child = -1;
+      n.narrow = false;
+    }
+    std::vector<int> nchild(nodes_.size(), 0);
+    for (size_t i = 0; i < nodes_.size(); ++i) {
+      Node &n = nodes_[i];
+      for (size_t k = 0; k < n.parents.size(); ++k) {
+        Node &p = nodes_[n.parents[k]];
+        nchild[n.parents[k]]++;
+        if (n.type == CONCAT_LAYER) {
+          if (p.concat_child >= 0) return why = "a layer feeds two concat layers", false;
+          if (n.parents[0] == n.parents[1]) return why = "a concat of a layer with itself", false;
+          p.concat_child = (int)i;
+          p.concat_slot = (int)k;
+        }
+      }
+    }
+    for (size_t i = 0; i < nodes_.size(); ++i) {
+      Node &n = nodes_[i];
+      const bool is_final = (int)i == final_;
+      switch (n.type) {
+        case CONV_LAYER:
+          if (n.kernel != 3 || n.padding != 1 || n.stride != 1) return why = "a convolution that is not 3x3/pad 1/stride 1", false;
+          if (n.parents.empty() ? n.in_c > 32 : n.in_c % 32 != 0) return why = "a convolution whose C_in is not a multiple of 32", false;
+          if (n.out_c % 32 != 0) {
+            if (!is_final || n.out_c > 32) return why = "a hidden convolution whose C_out is not a multiple of 32", false;
+            n.narrow = true;
+          }
+          break;
+        case UPSAMPLING_LAYER:
+          if (n.kernel != 2 || n.parents.empty() || n.in_c % 32 || n.out_c % 32)
+            return why = "an upsampling layer that is not scale 2 with channels in multiples of 32", false;
+          break;
+        case MAX_POOL_LAYER:
+          if (n.kernel != 2 || n.stride != 2 || n.parents.empty() || n.in_c % 32 || nchild[i] != 1 || n.concat_child >= 0)
+            return why = "a max pool that is not 2x2/stride 2 with one consumer", false;
+          break;
+        case CONCAT_LAYER:
+          if (n.c1 % 32 || n.c2 % 32 || n.concat_child >= 0 || is_final) return why = "a concat with channel counts off multiples of 32", false;
+          break;
+        default:
+          return why = "an unsupported layer type", false;
+      }
+      if (is_final && n.type != CONV_LAYER) return why = "a final layer that is not a convolution", false;
+      if (n.parents.empty() && n.type != CONV_LAYER) return why = "an input layer that is not a convolution", false;
+      n.cip = n.parents.empty() ? 32 : pad32(n.in_c);
+      n.cop = pad32(n.out_c);
+    }
+    return true;
+  }
+
+  void ensure_batch_bf16(int batch) {
+    const size_t b = (size_t)batch;
+    size_t max_dz = 0;
+    for (Node &n : nodes_) {
+      const size_t pix = b * (size_t)n.out_h * n.out_w;
+      if (n.has_params()) {
+        n.zb.ensure(2 * pix * n.cop);
+        n.coef.ensure(sizeof(float) * (size_t)unet_bn_coef_floats(n.cop));
+        const size_t in_pix_tiles = (size_t)unet_conv3x3_stat_tiles(n.in_h, n.in_w);
+        const size_t parts = n.type == CONV_LAYER ? b * in_pix_tiles : 4 * b * in_pix_tiles;
+        n.stat_partials.ensure(sizeof(float) * parts * n.cop * 2);
+        max_dz = std::max(max_dz, 2 * pix * n.cop);
+        const size_t taps = n.type == CONV_LAYER ? 9 : 4;
+        n.w_fwd.ensure(2 * taps * (size_t)n.cop * n.cip);
+        n.w_bwd.ensure(2 * taps * (size_t)n.cop * n.cip);
+      }
+      if (n.type == MAX_POOL_LAYER) n.mask.ensure(pix * n.cop);
+      if (n.narrow) {  // fp32 side buffers of the final layer
+        const size_t fb = sizeof(float) * b * (size_t)n.out_elems();
+        n.z.ensure(fb);
+        n.bn.ensure(fb);
+        n.act.ensure(fb);
+        n.grad_out.ensure(fb);
+      } else if (n.concat_child < 0) {
+        n.yb.ensure(2 * pix * n.cop);
+      }
+      if (!n.narrow) n.gb.ensure(2 * pix * n.cop);
+    }
+    // activation placement (after the concat buffers exist)
+    for (Node &n : nodes_) {
+      if (n.narrow) continue;
+      if (n.concat_child >= 0) {
+        Node &c = nodes_[n.concat_child];
+        n.y_ptr = c.yb.u16() + (n.concat_slot == 0 ? 0 : c.c1);
+        n.y_ld = c.cop;
+      } else {
+        n.y_ptr = n.yb.u16();
+        n.y_ld = n.cop;
+      }
+    }
+    Node &f = nodes_[final_];
+    scratch_g1_.ensure(sizeof(float) * b * (size_t)f.out_elems());
+    scratch_g2_.ensure(sizeof(float) * b * (size_t)f.out_elems());
+    dz16_.ensure(max_dz);
+    x16_.ensure(2 * b * (size_t)in_h_ * in_w_ * 32);
+    in_images_.ensure(sizeof(float) * b * (size_t)in_c_ * in_h_ * in_w_);
+    in_masks_.ensure(sizeof(float) * b * (size_t)f.out_h * f.out_w);
+    loss_values_.ensure(sizeof(float) * 3 * b);
+    params_dirty_ = true;
+  }
+
+  // fp32 master weights [C_in][C_out][k][k] -> packed bf16 operands
+  void pack_all_weights() {
+    for (Node &n : nodes_)
+      if (n.has_params())
+        UNET_CALL(unet_pack_weights_bf16(params_.f32() + n.param_off, n.w_fwd.u16(), n.w_bwd.u16(), n.in_c, n.out_c,
+                                         n.cip, n.cop, n.type == CONV_LAYER ? 3 : 2, stream_));
+    params_dirty_ = false;
+  }
+
+  void forward_node_bf16(Node &n, int batch, bool inference) {
+    const int64_t out_pix = (int64_t)batch * n.out_h * n.out_w;
+    switch (n.type) {
+      case CONV_LAYER:
+      case UPSAMPLING_LAYER: {
+        const uint16_t *in = n.parents.empty() ? x16_.u16() : nodes_[n.parents[0]].y_ptr;
+        const int in_ld = n.parents.empty() ? 32 : nodes_[n.parents[0]].y_ld;
+        const float *w = params_.f32() + n.param_off;
+        const float *bias = w + (n.num_wb - n.out_c);
+        const float *gb = w + n.num_wb;
+        float *parts = (inference || n.narrow) ? nullptr : n.stat_partials.f32();
+        int num_parts;
+        if (n.type == CONV_LAYER) {
+          UNET_CALL(unet_conv3x3_bf16(in, in_ld, n.w_fwd.u16(), bias, n.out_c, n.zb.u16(), n.cop, parts, batch, n.in_h,
+                                      n.in_w, n.cip, n.cop, 0, stream_));
+          num_parts = batch * unet_conv3x3_stat_tiles(n.in_h, n.in_w);
+        } else {
+          UNET_CALL(unet_tconv2x2_bf16(in, in_ld, n.w_fwd.u16(), bias, n.out_c, n.zb.u16(), n.cop, parts, batch, n.in_h,
+                                       n.in_w, n.cip, n.cop, stream_));
+          num_parts = 4 * batch * unet_conv3x3_stat_tiles(n.in_h, n.in_w);
+        }
+        if (n.narrow) {
+          // final layer: BN + activation (+ loss) on the fp32 kernels, [N,C,H,W] with C = out_c
+          UNET_CALL(unet_nhwc_bf16_to_nchw_f32(n.zb.u16(), n.z.f32(), batch, n.out_c, n.out_h, n.out_w, n.cop, stream_));
+          if (inference)
+            UNET_CALL(unet_batch_norm_inference_f32(n.z.f32(), n.bn.f32(), gb, n.running.f32(), n.out_h, n.out_w,
+                                                    n.out_c, batch, stream_));
+          else
+            UNET_CALL(unet_batch_norm_train_f32(n.z.f32(), n.bn.f32(), gb, n.batch_stats.f32(), n.running.f32(),
+                                                n.out_c, n.out_h, n.out_w, batch, stream_));
+          const int64_t out_n = (int64_t)batch * n.out_elems();
+          if (n.activation == SIGMOID)
+            UNET_CALL(unet_sigmoid_f32(n.bn.f32(), n.act.f32(), out_n, stream_));
+          else
+            UNET_CALL(unet_relu_f32(n.bn.f32(), n.act.f32(), out_n, stream_));
+          break;
+        }
+        if (inference)
+          UNET_CALL(unet_bn_inference_coef_bf16(gb, n.running.f32(), n.out_c, n.cop, n.coef.f32(), stream_));
+        else
+          UNET_CALL(unet_bn_finalize_bf16(parts, num_parts, n.out_c, n.cop, out_pix, gb, n.batch_stats.f32(),
+                                          n.running.f32(), n.coef.f32(), stream_));
+        const int act = (n.type == CONV_LAYER && n.activation == SIGMOID) ? 1 : 0;
+        UNET_CALL(unet_bn_act_bf16(n.zb.u16(), n.cop, n.y_ptr, n.y_ld, n.coef.f32(), n.cop, out_pix, act, stream_));
+        break;
+      }
+      case MAX_POOL_LAYER: {
+        const Node &p = nodes_[n.parents[0]];
+        UNET_CALL(unet_max_pool2x2_bf16(p.y_ptr, p.y_ld, n.y_ptr, n.y_ld, n.mask.u8(), batch, n.in_h, n.in_w, n.cop,
+                                        stream_));
+        break;
+      }
+      case CONCAT_LAYER:
+        break;  // both parents already wrote their slices of this layer's buffer
+      default:
+        throw std::runtime_error("unsupported layer type in forward");
+    }
+  }
+
+  void backward_node_bf16(Node &n, int batch) {
+    const int64_t out_pix = (int64_t)batch * n.out_h * n.out_w;
+    switch (n.type) {
+      case CONV_LAYER:
+      case UPSAMPLING_LAYER: {
+        const float *w = params_.f32() + n.param_off;
+        float *gw = grads_.f32() + n.param_off;
+        float *gbias = gw + (n.num_wb - n.out_c);
+        uint16_t *dz = dz16_.u16();
+        if (n.narrow) {
+          // fp32: activation backward, BN backward, bias gradient; then dz -> NHWC bf16 (padded with zeros)
+          const int64_t out_n = (int64_t)batch * n.out_elems();
+          float *g2 = scratch_g2_.f32(), *g1 = scratch_g1_.f32();
+          if (n.activation == SIGMOID)
+            UNET_CALL(unet_sigmoid_backward_f32(n.grad_out.f32(), n.act.f32(), g2, out_n, stream_));
+          else
+            UNET_CALL(unet_relu_backward_f32(n.grad_out.f32(), n.bn.f32(), g2, out_n, stream_));
+          UNET_CALL(unet_batch_norm_backward_f32(g2, n.z.f32(), n.batch_stats.f32(), w + n.num_wb, g1, gw + n.num_wb,
+                                                 n.out_c, n.out_h, n.out_w, batch, stream_));
+          UNET_CALL(unet_nchw_f32_to_nhwc_bf16(g1, dz, batch, n.out_c, n.out_h, n.out_w, n.cop, n.cop, stream_));
+          // bias gradient = per-channel sum of dz: reuse the BN statistics reduction (sum x lands at [2c])
+          UNET_CALL(unet_batch_norm_train_f32(g1, g2, w + n.num_wb, n.coef.f32(), nullptr, n.out_c, n.out_h, n.out_w,
+                                              batch, stream_));
+          for (int c = 0; c < n.out_c; ++c)
+            UNET_CALL(unet_memcpy_d2d(gbias + c, n.coef.f32() + 2 * c, sizeof(float), stream_));
+        } else {
+          const uint16_t *d1 = n.g_written ? n.gb.u16() : n.g2_ptr;
+          const int l1 = n.g_written ? n.cop : n.g2_ld;
+          const uint16_t *d2 = (n.g_written && n.g2_ptr) ? n.g2_ptr : nullptr;
+          if (!d1) return;  // not on a path to the loss
+          const int act = (n.type == CONV_LAYER && n.activation == SIGMOID) ? 1 : 0;
+          UNET_CALL(unet_bn_act_backward_bf16(d1, l1, d2, n.g2_ld, n.zb.u16(), n.cop, n.coef.f32(), w + n.num_wb, dz,
+                                              n.cop, gw + n.num_wb, gbias, n.out_c, n.cop, out_pix, act, stream_));
+        }
+        const uint16_t *x = n.parents.empty() ? x16_.u16() : nodes_[n.parents[0]].y_ptr;
+        const int x_ld = n.parents.empty() ? 32 : nodes_[n.parents[0]].y_ld;
+        if (!n.parents.empty()) {
+          Node &p = nodes_[n.parents[0]];
+          if (n.type == CONV_LAYER)
+            UNET_CALL(unet_conv3x3_bf16(dz, n.cop, n.w_bwd.u16(), nullptr, 0, p.gb.u16(), p.cop, nullptr, batch, n.in_h,
+                                        n.in_w, n.cop, n.cip, p.g_written ? 1 : 0, stream_));
+          else
+            UNET_CALL(unet_tconv2x2_dgrad_bf16(dz, n.cop, n.w_bwd.u16(), p.gb.u16(), p.cop, batch, n.in_h, n.in_w, n.cip,
+                                               n.cop, p.g_written ? 1 : 0, stream_));
+          p.g_written = true;
+        }
+        if (n.type == CONV_LAYER)
+          UNET_CALL(unet_conv3x3_wgrad_bf16(dz, n.cop, x, x_ld, gw, batch, n.in_h, n.in_w, n.cip, n.cop, n.in_c, n.out_c,
+                                            stream_));
+        else
+          UNET_CALL(unet_tconv2x2_wgrad_bf16(dz, n.cop, x, x_ld, gw, batch, n.in_h, n.in_w, n.cip, n.cop, n.in_c,
+                                             n.out_c, stream_));
+        break;
+      }
+      case MAX_POOL_LAYER: {
+        if (!n.g_written) return;
+        Node &p = nodes_[n.parents[0]];
+        UNET_CALL(unet_max_pool2x2_backward_bf16(n.gb.u16(), n.cop, n.mask.u8(), p.gb.u16(), p.cop, batch, n.in_h, n.in_w,
+                                                 n.cop, p.g_written ? 1 : 0, stream_));
+        p.g_written = true;
+        break;
+      }
+      case CONCAT_LAYER: {
+        if (!n.g_written) return;
+        Node &a = nodes_[n.parents[0]], &b = nodes_[n.parents[1]];
+        a.g2_ptr = n.gb.u16();
+        a.g2_ld = n.cop;
+        b.g2_ptr = n.gb.u16() + n.c1;
+        b.g2_ld = n.cop;
+        break;
+      }
+      default:
+        throw std::runtime_error("unsupported layer type in backward");
+    }
+  }
+
   std::vector<Node> nodes_;
   LossFunction loss_ = LossFunction::kDiceLoss;
   int final_ = -1;
@@ -658,6 +964,9 @@ class Net {
   int step_count_ = 0;
   uint64_t seed_ = 0;
   bool params_dirty_ = true;
+  bool use_bf16_ = false;
+  DeviceBuffer x16_;      // network input as NHWC bf16, channels padded to 32
+  DeviceBuffer dz16_;     // scratch: gradient w.r.t. a layer's pre-BN output
   bool verbose_ = true;
   unet_stream_t stream_ = nullptr;
   int64_t bucket_bytes_ = 8 << 20;
