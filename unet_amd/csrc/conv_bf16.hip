@@ -631,7 +631,7 @@ static int run_wgrad(int taps, const WgradArgs &base, float *grad, int Ci, int C
   a.chunksY = (a.H + 7) / 8;
   a.total_chunks = a.N * a.chunksX * a.chunksY;
   const int tiles = (a.CoP / 64) * (a.CiP / 64);
-  int splits = (1024 + tiles - 1) / tiles;
+  int splits = (512 + tiles - 1) / tiles;
   if (splits > a.total_chunks) splits = a.total_chunks;
   if (splits < 1) splits = 1;
   a.chunks_per_split = (a.total_chunks + splits - 1) / splits;

@@ -44,34 +44,56 @@ struct ChanBwd {
   float c0, k1, k2, pad;  // dz = c0*(g - k1 - xhat*k2): c0 = gamma*invb, k1 = dbeta/M, k2 = dgamma/M
 };
 
+// Sums column pairs (2c, 2c+1) of partials [P][CoP][2] with one wavefront per
+// channel: lanes stride over the P partials, accumulate in double and combine
+// with xor shuffles (fixed order, so the result is reproducible).
+__device__ __forceinline__ void wave_sum_partials(const float *__restrict__ partials, int P, int CoP, int c,
+                                                   double &s, double &q) {
+  const int lane = threadIdx.x & 63;
+  double a = 0, b = 0;
+  for (int p = lane; p < P; p += 64) {
+    const float2 v = *reinterpret_cast<const float2 *>(partials + ((i64)p * CoP + c) * 2);
+    a += v.x;
+    b += v.y;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    a += __shfl_xor(a, o, 64);
+    b += __shfl_xor(b, o, 64);
+  }
+  s = a;
+  q = b;
+}
+
 // partials [P][CoP][2] (sum, sum of squares) -> batch_stats, running stats, ChanFwd
-__global__ void bn_finalize_fwd_kernel(const float *__restrict__ partials, int P, int C, int CoP, float M,
-                                       const float *__restrict__ gb, float *__restrict__ batch_stats,
-                                       float *__restrict__ running, ChanFwd *__restrict__ out) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void bn_finalize_fwd_kernel(const float *__restrict__ partials, int P, int C,
+                                                              int CoP, float M, const float *__restrict__ gb,
+                                                              float *__restrict__ batch_stats,
+                                                              float *__restrict__ running,
+                                                              ChanFwd *__restrict__ out) {
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (c >= CoP) return;
   ChanFwd r{0.f, 0.f, 0.f, 0.f};
   if (c < C) {
-    double s = 0, q = 0;
-    for (int p = 0; p < P; ++p) {
-      s += partials[((i64)p * CoP + c) * 2];
-      q += partials[((i64)p * CoP + c) * 2 + 1];
-    }
+    double s, q;
+    wave_sum_partials(partials, P, CoP, c, s, q);
     const float mean = (float)(s / M);
     float var = (float)(q / M - (s / M) * (s / M));
     var = var < 0.f ? 0.f : var;
-    batch_stats[2 * c] = (float)s;
-    batch_stats[2 * c + 1] = (float)q;
-    if (running) {
-      running[2 * c] = running[2 * c] * BN_MOMENTUM + (1.0f - BN_MOMENTUM) * mean;
-      running[2 * c + 1] = running[2 * c + 1] * BN_MOMENTUM + (1.0f - BN_MOMENTUM) * var;
+    if ((threadIdx.x & 63) == 0) {
+      batch_stats[2 * c] = (float)s;
+      batch_stats[2 * c + 1] = (float)q;
+      if (running) {
+        running[2 * c] = running[2 * c] * BN_MOMENTUM + (1.0f - BN_MOMENTUM) * mean;
+        running[2 * c + 1] = running[2 * c + 1] * BN_MOMENTUM + (1.0f - BN_MOMENTUM) * var;
+      }
     }
     r.a = gb[2 * c] / (sqrtf(var) + BN_EPS);
     r.b = gb[2 * c + 1] - r.a * mean;
     r.mean = mean;
     r.invb = 1.0f / sqrtf(var + BN_EPS);
   }
-  out[c] = r;
+  if ((threadIdx.x & 63) == 0) out[c] = r;
 }
 
 // inference: a, b from the running statistics
@@ -183,25 +205,25 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const bf16_t *__rest
 }
 
 // sums partials; writes grad_gb[2c] = dgamma, [2c+1] = dbeta and the ChanBwd record
-__global__ void bn_finalize_bwd_kernel(const float *__restrict__ partials, int P, int C, int CoP, float M,
-                                       const float *__restrict__ gb, const ChanFwd *__restrict__ cf,
-                                       float *__restrict__ grad_gb, ChanBwd *__restrict__ out) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void bn_finalize_bwd_kernel(const float *__restrict__ partials, int P, int C,
+                                                              int CoP, float M, const float *__restrict__ gb,
+                                                              const ChanFwd *__restrict__ cf,
+                                                              float *__restrict__ grad_gb, ChanBwd *__restrict__ out) {
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (c >= CoP) return;
   ChanBwd r{0.f, 0.f, 0.f, 0.f};
   if (c < C) {
-    double dg = 0, db = 0;
-    for (int p = 0; p < P; ++p) {
-      dg += partials[((i64)p * CoP + c) * 2];
-      db += partials[((i64)p * CoP + c) * 2 + 1];
+    double dg, db;
+    wave_sum_partials(partials, P, CoP, c, dg, db);
+    if ((threadIdx.x & 63) == 0) {
+      grad_gb[2 * c] = (float)dg;
+      grad_gb[2 * c + 1] = (float)db;
     }
-    grad_gb[2 * c] = (float)dg;
-    grad_gb[2 * c + 1] = (float)db;
     r.c0 = gb[2 * c] * cf[c].invb;
     r.k1 = (float)(db / M);
     r.k2 = (float)(dg / M);
   }
-  out[c] = r;
+  if ((threadIdx.x & 63) == 0) out[c] = r;
 }
 
 // pass 2: dz = c0*(g - k1 - xhat*k2) (bf16) and per-block sums of dz (bias gradient)
@@ -263,14 +285,17 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16_t *__restr
   }
 }
 
-// out[c] = sum_p partial[p][c], c < C
-__global__ void column_sum_kernel(const float *__restrict__ partial, int P, int C, int stride,
-                                  float *__restrict__ out) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+// out[c] = sum_p partial[p][c], c < C: one wavefront per channel
+__global__ __launch_bounds__(256) void column_sum_kernel(const float *__restrict__ partial, int P, int C, int stride,
+                                                         float *__restrict__ out) {
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (c >= C) return;
+  const int lane = threadIdx.x & 63;
   double s = 0;
-  for (int p = 0; p < P; ++p) s += partial[(i64)p * stride + c];
-  out[c] = (float)s;
+  for (int p = lane; p < P; p += 64) s += partial[(i64)p * stride + c];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (lane == 0) out[c] = (float)s;
 }
 
 // ---- 2x2 / stride 2 max pool -------------------------------------------------------
@@ -381,7 +406,7 @@ int unet_bn_finalize_bf16(const float *stat_partials, int num_partials, int C, i
                           unet_stream_t s) {
   UNET_REQUIRE(stat_partials && gamma_beta && batch_stats && coef, "unet_bn_finalize_bf16: NULL pointer");
   UNET_REQUIRE(num_partials > 0 && C > 0 && CoP >= C && count > 0, "unet_bn_finalize_bf16: bad sizes");
-  hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(cdiv_u(CoP, 64)), dim3(64), 0, as_stream(s), stat_partials,
+  hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(cdiv_u(CoP, 4)), dim3(256), 0, as_stream(s), stat_partials,
                      num_partials, C, CoP, (float)count, gamma_beta, batch_stats, running_stats,
                      reinterpret_cast<ChanFwd *>(coef));
   UNET_LAUNCH_CHECK("bn_finalize_fwd_kernel");
@@ -445,7 +470,7 @@ int unet_bn_act_backward_bf16(const uint16_t *dy1, int ld1, const uint16_t *dy2,
     hipLaunchKernelGGL(bn_bwd_reduce_kernel<ACT_>, dim3(pl.blocks), dim3(256), lds1, as_stream(s), dy1, ld1, dy2,  \
                        ld2, z, z_ld, cf, pl.CG, pl.PL, (i64)pixels, pl.ppb, partial, CoP);                          \
     UNET_LAUNCH_CHECK("bn_bwd_reduce_kernel");                                                                      \
-    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(cdiv_u(CoP, 64)), dim3(64), 0, as_stream(s),                    \
+    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(cdiv_u(CoP, 4)), dim3(256), 0, as_stream(s),                    \
                        (const float *)partial, pl.blocks, C, CoP, (float)pixels, gamma_beta, cf, grad_gb, cb);      \
     UNET_LAUNCH_CHECK("bn_finalize_bwd_kernel");                                                                    \
     hipLaunchKernelGGL(bn_bwd_apply_kernel<ACT_>, dim3(pl.blocks), dim3(256), lds2, as_stream(s), dy1, ld1, dy2,   \
@@ -458,7 +483,7 @@ int unet_bn_act_backward_bf16(const uint16_t *dy1, int ld1, const uint16_t *dy2,
   else BWD_LAUNCH(2);
 #undef BWD_LAUNCH
   if (grad_bias) {
-    hipLaunchKernelGGL(column_sum_kernel, dim3(cdiv_u(C, 64)), dim3(64), 0, as_stream(s), (const float *)bias_part,
+    hipLaunchKernelGGL(column_sum_kernel, dim3(cdiv_u(C, 4)), dim3(256), 0, as_stream(s), (const float *)bias_part,
                        pl.blocks, C, CoP, grad_bias);
     UNET_LAUNCH_CHECK("column_sum_kernel");
   }
