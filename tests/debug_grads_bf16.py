@@ -1,5 +1,5 @@
 import os, sys
-sys.path.insert(0, "tests"); sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ["UNET_QUIET"] = "1"
 import numpy as np, torch, torch_ref
 import neural_net as nn
