@@ -67,6 +67,11 @@ struct ConvArgs {
   int accumulate;
   int tilesX;
   int co_valid;          // bias has this many entries
+  // TAPS == 1 only: the four (i,j) phases of a 2x2 stride-2 transposed convolution in one launch.
+  int out_phases;        // 4: blockIdx.y also selects the output phase (forward); else 1
+  int k_phases;          // 4: the reduction also runs over the input phases (data gradient); else 1
+  i64 wt_phase_stride;   // elements between the packed weights of consecutive phases
+  i64 stats_phase_stride;
 };
 
 constexpr int PITCH = 80;  // bytes per LDS row of 32 bf16 (64 B payload + 16 B pad)
@@ -83,7 +88,19 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
   unsigned char *ldsW = lds, *ldsX = lds + W_BYTES;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int tile = blockIdx.x, co0 = blockIdx.y * BN;
+  const int tile = blockIdx.x;
+  int co_blk = blockIdx.y, out_oy = a.out_oy, out_ox = a.out_ox;
+  const bf16_t *wt = a.wt;
+  float *stats = a.stats;
+  if (TAPS == 1 && a.out_phases > 1) {
+    const int cob = a.CoP / BN, ph = co_blk / cob;
+    co_blk -= ph * cob;
+    out_oy = ph >> 1;
+    out_ox = ph & 1;
+    wt += ph * a.wt_phase_stride;
+    if (stats) stats += ph * a.stats_phase_stride;
+  }
+  const int co0 = co_blk * BN;
   const i64 n = blockIdx.z;
   const int y0 = (tile / a.tilesX) * 16, x0 = (tile % a.tilesX) * 16;
   const bf16_t *in_n = a.in + n * (i64)a.Hin * a.Win * a.in_ld;
@@ -99,14 +116,23 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
     const int iy = (TAPS == 9) ? y : y * a.in_s + a.in_oy, ix = (TAPS == 9) ? x : x * a.in_s + a.in_ox;
     xoff[i] = ok ? (iy * a.Win + ix) * a.in_ld + part * 8 : -1;
   }
-  const bf16_t *w_thread = a.wt + (i64)co0 * a.Ci;  // + (tap*CoP + co)*Ci + part*8 + k0
+  const bf16_t *w_thread = wt + (i64)co0 * a.Ci;  // + (tap*CoP + co)*Ci + part*8 + k0
 
+  const int nk1 = a.Ci / 32;  // chunks per reduction phase
   uint4 xr[XI], wr[WI];
-  auto load_chunk = [&](int k0) {
+  auto load_chunk = [&](int kc) {
+    int k0 = kc * 32;
+    i64 xo = k0, wo = k0;
+    if (TAPS == 1 && a.k_phases > 1) {
+      const int ph = kc / nk1;
+      k0 = (kc - ph * nk1) * 32;
+      xo = k0 + (i64)((ph >> 1) * a.Win + (ph & 1)) * a.in_ld;
+      wo = k0 + ph * a.wt_phase_stride;
+    }
 #pragma unroll
     for (int i = 0; i < XI; ++i) {
       xr[i] = make_uint4(0, 0, 0, 0);
-      if (xoff[i] >= 0) xr[i] = *reinterpret_cast<const uint4 *>(in_n + xoff[i] + k0);
+      if (xoff[i] >= 0) xr[i] = *reinterpret_cast<const uint4 *>(in_n + xoff[i] + xo);
     }
 #pragma unroll
     for (int i = 0; i < WI; ++i) {
@@ -114,7 +140,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
       const int tap = row / BN, co = row % BN;
       wr[i] = make_uint4(0, 0, 0, 0);
       if (WCH % 256 == 0 || c < WCH)
-        wr[i] = *reinterpret_cast<const uint4 *>(w_thread + ((i64)tap * a.CoP + co) * a.Ci + k0 + part * 8);
+        wr[i] = *reinterpret_cast<const uint4 *>(w_thread + ((i64)tap * a.CoP + co) * a.Ci + wo + part * 8);
     }
   };
   auto store_chunk = [&]() {
@@ -141,12 +167,27 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
   const int a_lane = (lane & 31) * PITCH + (lane >> 5) * 16;
   const int b_lane = ((wave * 4 + ((lane & 31) >> 4)) * HALO + (lane & 15)) * PITCH + (lane >> 5) * 16;
 
-  const int nk = a.Ci / 32;
+  // bias of this lane's accumulator channels, fetched now so that its latency hides behind the K loop
+  f32x4 bias_r[MF][4];
+#pragma unroll
+  for (int m = 0; m < MF; ++m)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int ch = co0 + m * 32 + 8 * g + 4 * (lane >> 5);
+      bias_r[m][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (a.bias) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (ch + j < a.co_valid) bias_r[m][g][j] = a.bias[ch + j];
+      }
+    }
+
+  const int nk = (TAPS == 1) ? nk1 * a.k_phases : nk1;
   load_chunk(0);
   store_chunk();
   __syncthreads();
   for (int kc = 0; kc < nk; ++kc) {
-    if (kc + 1 < nk) load_chunk((kc + 1) * 32);
+    if (kc + 1 < nk) load_chunk(kc + 1);
 #pragma unroll
     for (int tap = 0; tap < TAPS; ++tap) {
       const int kh = (TAPS == 9) ? tap / 3 : 0, kw = (TAPS == 9) ? tap % 3 : 0;
@@ -185,58 +226,37 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
       for (int g = 0; g < 4; ++g) {
         const int ch = m * 32 + 8 * g + 4 * (lane >> 5);
         f32x4 v = {acc[m][q][4 * g], acc[m][q][4 * g + 1], acc[m][q][4 * g + 2], acc[m][q][4 * g + 3]};
-        if (a.bias) {
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            if (co0 + ch + j < a.co_valid) v[j] += a.bias[co0 + ch + j];
-        }
+        v += bias_r[m][g];
         const bf16x4 h = __builtin_convertvector(v, bf16x4);
         *reinterpret_cast<bf16x4 *>(stage + pix * OP + ch * 2) = h;
       }
     }
   __syncthreads();
 
-  // ---- per-tile batch-norm partial sums (of the rounded values) ----
-  if (a.stats) {
-    constexpr int CP = BN / 2;        // channel pairs
-    constexpr int SL = 256 / CP;      // pixel slices
-    constexpr int PPS = 256 / SL;     // pixels per slice
-    float *red = reinterpret_cast<float *>(lds + 256 * OP);
-    const int cp = tid % CP, sl = tid / CP;
-    float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
-    for (int i = 0; i < PPS; ++i) {
-      const int pix = sl * PPS + i;
-      if (y0 + (pix >> 4) < a.Ho && x0 + (pix & 15) < a.Wo) {
-        const uint32_t u = *reinterpret_cast<const uint32_t *>(stage + pix * OP + cp * 4);
-        const float v0 = bf16_to_f32(u & 0xffffu), v1 = bf16_to_f32(u >> 16);
-        s0 += v0; q0 += v0 * v0; s1 += v1; q1 += v1 * v1;
-      }
-    }
-    *reinterpret_cast<f32x4 *>(red + (sl * CP + cp) * 4) = f32x4{s0, q0, s1, q1};
-    __syncthreads();
-    if (tid < BN) {
-      const int c2 = tid >> 1, odd = tid & 1;
-      float s = 0.f, q = 0.f;
-      for (int j = 0; j < SL; ++j) {
-        s += red[(j * CP + c2) * 4 + 2 * odd];
-        q += red[(j * CP + c2) * 4 + 2 * odd + 1];
-      }
-      float *dst = a.stats + ((n * gridDim.x + tile) * (i64)a.CoP + co0 + tid) * 2;
-      dst[0] = s;
-      dst[1] = q;
-    }
-  }
-
-  // ---- staging tile -> HBM, 16 bytes per lane, whole channel rows ----
-  constexpr int CH = BN / 8;  // 16-byte pieces per pixel
+  // ---- staging tile -> HBM, 16 bytes per lane, whole channel rows; the same pass
+  // accumulates the per-tile batch-norm partial sums of the rounded values ----
+  constexpr int CH = BN / 8;  // 16-byte pieces per pixel; a thread keeps one piece index
+  const int part = tid % CH;
   bf16_t *out_n = a.out + n * (i64)a.Hout * a.Wout * a.out_ld + co0;
+  float ssum[8], ssq[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) ssum[j] = ssq[j] = 0.f;
 #pragma unroll
   for (int i = 0; i < CH; ++i) {
-    const int c = tid + 256 * i, pix = c / CH, part = c % CH;
+    const int pix = tid / CH + i * (256 / CH);
     const int y = y0 + (pix >> 4), x = x0 + (pix & 15);
     if (y < a.Ho && x < a.Wo) {
       uint4 v = *reinterpret_cast<const uint4 *>(stage + pix * OP + part * 16);
-      bf16_t *dst = out_n + ((i64)(y * a.out_s + a.out_oy) * a.Wout + (x * a.out_s + a.out_ox)) * a.out_ld + part * 8;
+      if (stats) {
+        const uint32_t vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float lo = bf16_to_f32(vv[j] & 0xffffu), hi = bf16_to_f32(vv[j] >> 16);
+          ssum[2 * j] += lo; ssq[2 * j] += lo * lo;
+          ssum[2 * j + 1] += hi; ssq[2 * j + 1] += hi * hi;
+        }
+      }
+      bf16_t *dst = out_n + ((i64)(y * a.out_s + out_oy) * a.Wout + (x * a.out_s + out_ox)) * a.out_ld + part * 8;
       if (a.accumulate) {
         const uint4 o = *reinterpret_cast<const uint4 *>(dst);
         const uint32_t vv[4] = {v.x, v.y, v.z, v.w}, oo[4] = {o.x, o.y, o.z, o.w};
@@ -250,6 +270,30 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
         v = make_uint4(rr[0], rr[1], rr[2], rr[3]);
       }
       *reinterpret_cast<uint4 *>(dst) = v;
+    }
+  }
+  if (stats) {
+    // lanes with equal (lane % CH) hold the same 8 channels: butterfly over the other lane bits,
+    // then one partial per wave through LDS, summed in wave order (deterministic)
+#pragma unroll
+    for (int o = CH; o < 64; o <<= 1)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        ssum[j] += __shfl_xor(ssum[j], o, 64);
+        ssq[j] += __shfl_xor(ssq[j], o, 64);
+      }
+    float *red = reinterpret_cast<float *>(lds + 256 * OP);  // [wave][BN][2]
+    if (lane < CH) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        red[(wave * BN + lane * 8 + j) * 2] = ssum[j];
+        red[(wave * BN + lane * 8 + j) * 2 + 1] = ssq[j];
+      }
+    }
+    __syncthreads();
+    if (tid < 2 * BN) {
+      const float t = (red[tid] + red[2 * BN + tid]) + (red[4 * BN + tid] + red[6 * BN + tid]);
+      stats[((n * gridDim.x + tile) * (i64)a.CoP + co0) * 2 + tid] = t;
     }
   }
 }
@@ -274,7 +318,8 @@ int launch_conv(const ConvArgs &a, hipStream_t s) {
     attr_set[dev & 63] = true;
   }
   const int tilesY = (a.Ho + 15) / 16;
-  dim3 grid((unsigned)(tilesY * a.tilesX), (unsigned)(a.CoP / BN), (unsigned)a.N);
+  dim3 grid((unsigned)(tilesY * a.tilesX), (unsigned)(a.CoP / BN * (a.out_phases > 1 ? a.out_phases : 1)),
+            (unsigned)a.N);
   hipLaunchKernelGGL((conv_mfma_kernel<TAPS, BN>), grid, dim3(256), lds, s, a);
   UNET_LAUNCH_CHECK("conv_mfma_kernel");
   return UNET_OK;
@@ -416,20 +461,67 @@ __global__ __launch_bounds__(256, 1) void wgrad_mfma_kernel(const WgradArgs a) {
     }
 }
 
-// grad[(ci*Co + co)*taps_total + tap_index(t)] (+)= sum_split partial[split][t][co][ci]
-// tap_index: for 3x3, t; for the transposed conv phases, tap_base (one phase per launch).
+// grad[(ci*Co + co)*taps_total + tap_base + t] = sum_split partial[split][t][co][ci]
+// A workgroup owns 32 consecutive ci of one (t, co) row; its 8 groups of 32 lanes each add every
+// eighth split slice (128-byte coalesced reads), then the 8 partial sums are added in a fixed order.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restrict__ partial,
                                                            float *__restrict__ grad, int splits, int taps,
                                                            int CoP, int CiP, int Co, int Ci, int taps_total,
                                                            int tap_base) {
-  const i64 total = (i64)taps * Co * Ci;
-  for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (i64)gridDim.x * blockDim.x) {
-    const int ci = (int)(i % Ci);
-    const i64 r = i / Ci;
+  __shared__ float red[8][32];
+  const int ci_blocks = (Ci + 31) / 32;
+  const int lane32 = threadIdx.x & 31, grp = threadIdx.x >> 5;
+  const i64 rows = (i64)taps * Co * ci_blocks;
+  const i64 slice = (i64)taps * CoP * CiP;
+  for (i64 b = blockIdx.x; b < rows; b += gridDim.x) {
+    const int cb = (int)(b % ci_blocks);
+    const i64 r = b / ci_blocks;
     const int co = (int)(r % Co), t = (int)(r / Co);
-    double s = 0;
-    for (int k = 0; k < splits; ++k) s += partial[(((i64)k * taps + t) * CoP + co) * CiP + ci];
-    grad[((i64)ci * Co + co) * taps_total + tap_base + t] = (float)s;
+    const int ci = cb * 32 + lane32;
+    float s = 0.f;
+    if (ci < Ci) {
+      const float *p = partial + ((i64)t * CoP + co) * CiP + ci;
+      for (int k = grp; k < splits; k += 8) s += p[k * slice];
+    }
+    red[grp][lane32] = s;
+    __syncthreads();
+    if (grp == 0 && ci < Ci) {
+      float tot = red[0][lane32];
+#pragma unroll
+      for (int g = 1; g < 8; ++g) tot += red[g][lane32];
+      grad[((i64)ci * Co + co) * taps_total + tap_base + t] = tot;
+    }
+    __syncthreads();
+  }
+}
+
+// Same reduction for layers with many outputs and few split slices: a workgroup owns a
+// 32(ci) x 8(co) x taps box, reads it with 128-byte coalesced rows, transposes through LDS and
+// writes runs of 8*taps consecutive floats of the reference layout.
+__global__ __launch_bounds__(256) void wgrad_reduce_tile_kernel(const float *__restrict__ partial,
+                                                                float *__restrict__ grad, int splits, int taps,
+                                                                int CoP, int CiP, int Co, int Ci, int taps_total,
+                                                                int tap_base) {
+  __shared__ float tile[32][8 * 9 + 1];
+  const int lane32 = threadIdx.x & 31, grp = threadIdx.x >> 5;
+  const int ci0 = blockIdx.x * 32, co0 = blockIdx.y * 8;
+  const int ci = ci0 + lane32, co = co0 + grp;
+  const i64 slice = (i64)taps * CoP * CiP;
+  for (int t = 0; t < taps; ++t) {
+    float s = 0.f;
+    if (ci < Ci && co < Co) {
+      const float *p = partial + ((i64)t * CoP + co) * CiP + ci;
+      for (int k = 0; k < splits; ++k) s += p[k * slice];
+    }
+    tile[lane32][grp * taps + t] = s;
+  }
+  __syncthreads();
+  const int run = 8 * taps;
+  for (int idx = threadIdx.x; idx < 32 * run; idx += 256) {
+    const int cl = idx / run, rem = idx - cl * run;
+    const int col = rem / taps, t = rem - col * taps;
+    if (ci0 + cl < Ci && co0 + col < Co)
+      grad[((i64)(ci0 + cl) * Co + co0 + col) * taps_total + tap_base + t] = tile[cl][rem];
   }
 }
 
@@ -561,6 +653,7 @@ int unet_conv3x3_bf16(const uint16_t *in, int in_ld, const uint16_t *w_packed, c
   a.out_s = 1; a.out_oy = a.out_ox = 0; a.Hout = H; a.Wout = W; a.accumulate = accumulate;
   a.tilesX = (W + 15) / 16;
   a.co_valid = co_valid;
+  a.out_phases = a.k_phases = 1;
   const double flops = 2.0 * N * H * W * (double)CiP * CoP * 9;
   ProfScope prof(stat_partials || bias ? PROF_CONV_FWD_BF16 : PROF_CONV_DGRAD_BF16, flops,
                  2.0 * N * H * W * ((double)CiP + CoP), as_stream(s));
@@ -584,19 +677,17 @@ int unet_tconv2x2_bf16(const uint16_t *in, int in_ld, const uint16_t *w_packed, 
   const int tiles = unet_conv3x3_stat_tiles(H_in, W_in);
   ProfScope prof(PROF_TCONV_BF16, 2.0 * N * H_in * W_in * 4.0 * CiP * CoP,
                  2.0 * N * H_in * W_in * ((double)CiP + 4.0 * CoP), as_stream(s));
-  for (int ph = 0; ph < 4; ++ph) {
-    ConvArgs a{};
-    a.in = in; a.wt = w_packed + (i64)ph * CoP * CiP; a.bias = bias; a.out = out;
-    a.stats = stat_partials ? stat_partials + (i64)ph * N * tiles * CoP * 2 : nullptr;
-    a.N = N; a.Hin = H_in; a.Win = W_in; a.Ho = H_in; a.Wo = W_in; a.Ci = CiP; a.CoP = CoP;
-    a.in_ld = in_ld; a.out_ld = out_ld; a.in_s = 1; a.in_oy = a.in_ox = 0;
-    a.out_s = 2; a.out_oy = ph >> 1; a.out_ox = ph & 1; a.Hout = 2 * H_in; a.Wout = 2 * W_in; a.accumulate = 0;
-    a.tilesX = (W_in + 15) / 16;
-    a.co_valid = co_valid;
-    int rc = launch_conv_any(1, a, as_stream(s));
-    if (rc) return rc;
-  }
-  return UNET_OK;
+  ConvArgs a{};
+  a.in = in; a.wt = w_packed; a.bias = bias; a.out = out; a.stats = stat_partials;
+  a.N = N; a.Hin = H_in; a.Win = W_in; a.Ho = H_in; a.Wo = W_in; a.Ci = CiP; a.CoP = CoP;
+  a.in_ld = in_ld; a.out_ld = out_ld; a.in_s = 1; a.in_oy = a.in_ox = 0;
+  a.out_s = 2; a.out_oy = a.out_ox = 0; a.Hout = 2 * H_in; a.Wout = 2 * W_in; a.accumulate = 0;
+  a.tilesX = (W_in + 15) / 16;
+  a.co_valid = co_valid;
+  a.out_phases = 4; a.k_phases = 1;
+  a.wt_phase_stride = (i64)CoP * CiP;
+  a.stats_phase_stride = (i64)N * tiles * CoP * 2;
+  return launch_conv_any(1, a, as_stream(s));
 }
 
 // dX[n,h,w,ci] = sum_{i,j} sum_co dY[n,2h+i,2w+j,co] * W[ci,co,i,j];  w_packed_bwd = [phase][CiP][CoP]
@@ -611,17 +702,15 @@ int unet_tconv2x2_dgrad_bf16(const uint16_t *dy, int dy_ld, const uint16_t *w_pa
                "unet_tconv2x2_dgrad_bf16: one image must stay below 2^31 elements");
   ProfScope prof(PROF_TCONV_BF16, 2.0 * N * H_in * W_in * 4.0 * CiP * CoP,
                  2.0 * N * H_in * W_in * ((double)CiP + 4.0 * CoP), as_stream(s));
-  for (int ph = 0; ph < 4; ++ph) {
-    ConvArgs a{};
-    a.in = dy; a.wt = w_packed_bwd + (i64)ph * CiP * CoP; a.bias = nullptr; a.out = dx; a.stats = nullptr;
-    a.N = N; a.Hin = 2 * H_in; a.Win = 2 * W_in; a.Ho = H_in; a.Wo = W_in; a.Ci = CoP; a.CoP = CiP;
-    a.in_ld = dy_ld; a.out_ld = dx_ld; a.in_s = 2; a.in_oy = ph >> 1; a.in_ox = ph & 1;
-    a.out_s = 1; a.out_oy = a.out_ox = 0; a.Hout = H_in; a.Wout = W_in; a.accumulate = (ph > 0) || accumulate;
-    a.tilesX = (W_in + 15) / 16;
-    int rc = launch_conv_any(1, a, as_stream(s));
-    if (rc) return rc;
-  }
-  return UNET_OK;
+  ConvArgs a{};
+  a.in = dy; a.wt = w_packed_bwd; a.bias = nullptr; a.out = dx; a.stats = nullptr;
+  a.N = N; a.Hin = 2 * H_in; a.Win = 2 * W_in; a.Ho = H_in; a.Wo = W_in; a.Ci = CoP; a.CoP = CiP;
+  a.in_ld = dy_ld; a.out_ld = dx_ld; a.in_s = 2; a.in_oy = a.in_ox = 0;
+  a.out_s = 1; a.out_oy = a.out_ox = 0; a.Hout = H_in; a.Wout = W_in; a.accumulate = accumulate;
+  a.tilesX = (W_in + 15) / 16;
+  a.out_phases = 1; a.k_phases = 4;
+  a.wt_phase_stride = (i64)CiP * CoP;
+  return launch_conv_any(1, a, as_stream(s));
 }
 
 static int run_wgrad(int taps, const WgradArgs &base, float *grad, int Ci, int Co, int taps_total, int tap_base,
@@ -659,8 +748,15 @@ static int run_wgrad(int taps, const WgradArgs &base, float *grad, int Ci, int C
   else
     hipLaunchKernelGGL(wgrad_mfma_kernel<1>, grid, dim3(256), lds, s, a);
   UNET_LAUNCH_CHECK("wgrad_mfma_kernel");
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ew_grid((i64)taps * Co * Ci)), dim3(256), 0, s, (const float *)ws, grad,
-                     splits, taps, a.CoP, a.CiP, Co, Ci, taps_total, tap_base);
+  const i64 boxes = (i64)((Ci + 31) / 32) * ((Co + 7) / 8);
+  if (boxes >= 512 && splits <= 16) {
+    hipLaunchKernelGGL(wgrad_reduce_tile_kernel, dim3((unsigned)((Ci + 31) / 32), (unsigned)((Co + 7) / 8)), dim3(256), 0,
+                       s, (const float *)ws, grad, splits, taps, a.CoP, a.CiP, Co, Ci, taps_total, tap_base);
+  } else {
+    const i64 reduce_rows = (i64)taps * Co * ((Ci + 31) / 32);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(reduce_rows < 65536 ? reduce_rows : 65536)), dim3(256), 0,
+                       s, (const float *)ws, grad, splits, taps, a.CoP, a.CiP, Co, Ci, taps_total, tap_base);
+  }
   UNET_LAUNCH_CHECK("wgrad_reduce_kernel");
   return UNET_OK;
 }
