@@ -432,5 +432,23 @@ int main(int argc, char **argv) {
     printf("   mismatches: pad %zu v2 %zu\n", bad1, bad2);
     fflush(stdout);
   }
+  // weight gradient through the library (variant chosen by UNET_WGRAD_VARIANT)
+  float *d_grad;
+  CK(hipMalloc(&d_grad, max_w * 4 + 4096));
+  printf("wgrad (UNET_WGRAD_VARIANT=%s)\n", getenv("UNET_WGRAD_VARIANT") ? getenv("UNET_WGRAD_VARIANT") : "default");
+  for (auto &s : shapes) {
+    const double flops = 2.0 * N * s.H * s.H * (double)s.Ci * s.Co * 9;
+    float t = time_launch([&] {
+      if (unet_conv3x3_wgrad_bf16(d_out, s.Co, d_in, s.Ci, d_grad, N, s.H, s.H, s.Ci, s.Co, s.Ci, s.Co, nullptr)) {
+        fprintf(stderr, "wgrad failed: %s\n", unet_last_error());
+        exit(1);
+      }
+    }, 20);
+    std::vector<float> hg(64);
+    CK(hipMemcpy(hg.data(), d_grad, 64 * 4, hipMemcpyDeviceToHost));
+    double cs = 0;
+    for (float v : hg) cs += v;
+    printf("%dx%d %d->%d   %6.0f us  %5.0f TFLOP/s  checksum %.6g\n", s.H, s.H, s.Ci, s.Co, t, flops / t * 1e-6, cs);
+  }
   return 0;
 }

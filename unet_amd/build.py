@@ -21,6 +21,9 @@ HIP_LIB = os.path.join(LIBDIR, "libunet_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
              "-Wno-unused-variable", "-Wno-unused-but-set-variable"]
+# Per-file extra flags.  wgrad_bf16: MFMA accumulators stay in ordinary vector registers (no copies
+# to and from the accumulation half of the register file around the loop-carried accumulators).
+EXTRA_FLAGS = {"wgrad_bf16.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
 
 
 def _newer(target, sources):
@@ -44,7 +47,7 @@ def build_hip(force=False, verbose=False):
         obj = os.path.join(OBJDIR, os.path.basename(src)[:-4] + ".o")
         objs.append(obj)
         if force or _newer(obj, [src] + headers):
-            cmd = [HIPCC] + HIP_FLAGS + ["-c", src, "-o", obj]
+            cmd = [HIPCC] + HIP_FLAGS + EXTRA_FLAGS.get(os.path.basename(src), []) + ["-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd))
             procs.append((src, subprocess.Popen(cmd)))

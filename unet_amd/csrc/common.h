@@ -50,11 +50,15 @@ enum UnetProfKind {
   PROF_CONV_WGRAD_F32,
   PROF_TCONV_F32,
   PROF_BN_F32,
-  PROF_CONV_FWD_BF16,
-  PROF_CONV_DGRAD_BF16,
-  PROF_CONV_WGRAD_BF16,
-  PROF_TCONV_BF16,
-  PROF_BN_RELU_BF16,
+  PROF_CONV_FWD_BF16,      // conv_mfma_kernel<9,*> as forward
+  PROF_CONV_DGRAD_BF16,    // conv_mfma_kernel<9,*> as data gradient
+  PROF_CONV_WGRAD_BF16,    // wgrad_mfma_kernel<9>
+  PROF_WGRAD_REDUCE,       // wgrad_reduce(_tile)_kernel
+  PROF_TCONV_BF16,         // conv_mfma_kernel<1,*> (transposed conv forward and data gradient)
+  PROF_TCONV_WGRAD_BF16,   // wgrad_mfma_kernel<1>
+  PROF_BN_ACT_BF16,        // bn_act_kernel
+  PROF_BN_BWD_REDUCE_BF16, // bn_bwd_reduce_kernel
+  PROF_BN_BWD_APPLY_BF16,  // bn_bwd_apply_kernel
   PROF_POOL_BF16,
   PROF_KINDS
 };

@@ -26,30 +26,9 @@
 // taps / transposed weights).  TAPS = 1: 1x1 with strided input / output pixel
 // maps -- the four (i,j) phases of the 2x2 stride-2 transposed convolution.
 //
-// wgrad_mfma_kernel<TAPS>: dW[tap][co][ci] = sum_pixel dZ[pixel][co] * X[pixel + off(tap)][ci]
-//   - the reduction runs over pixels, which is the strided dimension of both
-//     NHWC operands; ds_read_b64_tr_b16 (the transposing LDS read of gfx950)
-//     delivers the [pixel][channel] LDS tiles as K-contiguous MFMA fragments;
-//   - a workgroup owns a 64(co) x 64(ci) block of all TAPS filter taps and a
-//     slice of the pixels (split-K); partial blocks go to a workspace and a
-//     second kernel adds the slices in a fixed order (deterministic) while
-//     converting to the reference's [C_in][C_out][k][k] fp32 layout.
-#include "common.h"
-
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef short s16x4 __attribute__((ext_vector_type(4)));
-typedef uint16_t bf16_t;
+#include "bf16_util.h"
 
 namespace {
-
-__device__ __forceinline__ float bf16_to_f32(uint32_t h) { return __uint_as_float(h << 16); }
-__device__ __forceinline__ uint32_t f32_to_bf16(float f) {
-  __bf16 h = (__bf16)f;
-  return (uint32_t) __builtin_bit_cast(unsigned short, h);
-}
 
 struct ConvArgs {
   const bf16_t *in;
@@ -331,223 +310,33 @@ int launch_conv_any(int taps, const ConvArgs &a, hipStream_t s) {
 }
 
 // ---------------------------------------------------------------------------
-// Weight gradient.
-// ---------------------------------------------------------------------------
-struct WgradArgs {
-  const bf16_t *dz;  // [N][Hz][Wz][dz_ld], CoP channels used
-  const bf16_t *x;   // [N][H][W][x_ld], CiP channels used
-  float *partial;    // [splits][TAPS][CoP][CiP] fp32
-  int N, H, W;       // logical pixel grid = x image size
-  int Hz, Wz;        // dz image size
-  int dz_ld, x_ld, CoP, CiP;  // partial-buffer dims (multiples of 64)
-  int z_c, x_c;               // channels present in dz / x (multiples of 8)
-  int dz_s, dz_oy, dz_ox;  // dz pixel of logical (y,x): (y*dz_s+dz_oy, x*dz_s+dz_ox)
-  int chunksX, chunksY;    // 8x16 pixel chunks per image
-  int chunks_per_split, total_chunks;
-};
-
-__device__ __forceinline__ bf16x8 tr_read_pair(const unsigned char *p0, const unsigned char *p1) {
-  // two transposing 64-bit LDS reads -> one 8-element K-contiguous MFMA fragment
-  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-      (__attribute__((address_space(3))) s16x4 *)(__attribute__((address_space(3))) void *)(p0));
-  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-      (__attribute__((address_space(3))) s16x4 *)(__attribute__((address_space(3))) void *)(p1));
-  typedef short s16x8 __attribute__((ext_vector_type(8)));
-  const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-  return __builtin_bit_cast(bf16x8, v);
-}
-
-constexpr int WP = 192;  // LDS row pitch (bytes) of a 64-channel pixel row: 4 rows x 64 B fall in 4 distinct bank quarters
-
-template <int TAPS>
-__global__ __launch_bounds__(256, 1) void wgrad_mfma_kernel(const WgradArgs a) {
-  constexpr int XR = (TAPS == 9) ? 10 : 8, XC = (TAPS == 9) ? 18 : 16;  // x patch (with halo for 3x3)
-  constexpr int XPIX = XR * XC, ZPIX = 128;
-  constexpr int XCH = XPIX * 8, XI = (XCH + 255) / 256;  // 16-byte pieces (8 per 64-channel row)
-  constexpr int ZCH = ZPIX * 8, ZI = ZCH / 256;
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  unsigned char *ldsZ = lds, *ldsX = lds + ZPIX * WP;
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int co0 = blockIdx.y * 64, ci0 = blockIdx.z * 64, split = blockIdx.x;
-  const int wm = wave >> 1, wn = wave & 1;  // wave's 32x32 block of the 64(co) x 64(ci) tile
-
-  f32x16 acc[TAPS];
-#pragma unroll
-  for (int t = 0; t < TAPS; ++t)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-
-  // transposing-read lane addresses: lane 4q+p of each 16-lane group supplies row q, 4-channel piece p
-  const int grp = lane >> 4, li = lane & 15, q = li >> 2, p = li & 3, h = grp >> 1;
-  const int z_lane = (8 * h + q) * WP + (wm * 32 + 16 * (grp & 1) + 4 * p) * 2;
-  const int x_lane = (8 * h + q) * WP + (wn * 32 + 16 * (grp & 1) + 4 * p) * 2;
-
-  const int c_begin = split * a.chunks_per_split;
-  const int c_end = min(a.total_chunks, c_begin + a.chunks_per_split);
-  const int per_img = a.chunksX * a.chunksY;
-
-  uint4 xr[XI], zr[ZI];
-  auto load_chunk = [&](int chunk) {
-    const int n = chunk / per_img, r = chunk - n * per_img;
-    const int y0 = (r / a.chunksX) * 8, x0 = (r % a.chunksX) * 16;
-    const bf16_t *x_n = a.x + (i64)n * a.H * a.W * a.x_ld + ci0;
-    const bf16_t *z_n = a.dz + (i64)n * a.Hz * a.Wz * a.dz_ld + co0;
-#pragma unroll
-    for (int i = 0; i < XI; ++i) {
-      const int c = tid + 256 * i, pix = c >> 3, part = c & 7;
-      const int py = pix / XC, px = pix - py * XC;
-      const int y = y0 + py - (TAPS == 9), x = x0 + px - (TAPS == 9);
-      xr[i] = make_uint4(0, 0, 0, 0);
-      if ((XCH % 256 == 0 || c < XCH) && y >= 0 && y < a.H && x >= 0 && x < a.W && ci0 + part * 8 < a.x_c)
-        xr[i] = *reinterpret_cast<const uint4 *>(x_n + ((i64)y * a.W + x) * a.x_ld + part * 8);
-    }
-#pragma unroll
-    for (int i = 0; i < ZI; ++i) {
-      const int c = tid + 256 * i, pix = c >> 3, part = c & 7;
-      const int y = y0 + (pix >> 4), x = x0 + (pix & 15);
-      zr[i] = make_uint4(0, 0, 0, 0);
-      if (y < a.H && x < a.W && co0 + part * 8 < a.z_c)
-        zr[i] = *reinterpret_cast<const uint4 *>(
-            z_n + ((i64)(y * a.dz_s + a.dz_oy) * a.Wz + (x * a.dz_s + a.dz_ox)) * a.dz_ld + part * 8);
-    }
-  };
-  auto store_chunk = [&]() {
-#pragma unroll
-    for (int i = 0; i < XI; ++i) {
-      const int c = tid + 256 * i;
-      if (XCH % 256 == 0 || c < XCH) *reinterpret_cast<uint4 *>(ldsX + (c >> 3) * WP + (c & 7) * 16) = xr[i];
-    }
-#pragma unroll
-    for (int i = 0; i < ZI; ++i) {
-      const int c = tid + 256 * i;
-      *reinterpret_cast<uint4 *>(ldsZ + (c >> 3) * WP + (c & 7) * 16) = zr[i];
-    }
-  };
-
-  if (c_begin < c_end) {
-    load_chunk(c_begin);
-    store_chunk();
-    __syncthreads();
-    for (int chunk = c_begin; chunk < c_end; ++chunk) {
-      if (chunk + 1 < c_end) load_chunk(chunk + 1);
-#pragma unroll
-      for (int ks = 0; ks < 8; ++ks) {  // K step = one 16-pixel row of the 8x16 chunk
-        const unsigned char *zp = ldsZ + ks * 16 * WP + z_lane;
-        const bf16x8 af = tr_read_pair(zp, zp + 4 * WP);
-#pragma unroll
-        for (int t = 0; t < TAPS; ++t) {
-          const int kh = (TAPS == 9) ? t / 3 : 0, kw = (TAPS == 9) ? t % 3 : 0;
-          const unsigned char *xp = ldsX + ((ks + kh) * XC + kw) * WP + x_lane;
-          const bf16x8 bfr = tr_read_pair(xp, xp + 4 * WP);
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, acc[t], 0, 0, 0);
-        }
-      }
-      __syncthreads();
-      if (chunk + 1 < c_end) {
-        store_chunk();
-        __syncthreads();
-      }
-    }
-  }
-  // partial[split][tap][co][ci]; accumulator reg r: co = (r&3) + 8*(r>>2) + 4*(lane>>5), ci = lane&31
-  float *dst = a.partial + (((i64)split * TAPS) * a.CoP + co0 + wm * 32) * a.CiP + ci0 + wn * 32 + (lane & 31);
-#pragma unroll
-  for (int t = 0; t < TAPS; ++t)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      dst[((i64)t * a.CoP + row) * a.CiP] = acc[t][r];
-    }
-}
-
-// grad[(ci*Co + co)*taps_total + tap_base + t] = sum_split partial[split][t][co][ci]
-// A workgroup owns 32 consecutive ci of one (t, co) row; its 8 groups of 32 lanes each add every
-// eighth split slice (128-byte coalesced reads), then the 8 partial sums are added in a fixed order.
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restrict__ partial,
-                                                           float *__restrict__ grad, int splits, int taps,
-                                                           int CoP, int CiP, int Co, int Ci, int taps_total,
-                                                           int tap_base) {
-  __shared__ float red[8][32];
-  const int ci_blocks = (Ci + 31) / 32;
-  const int lane32 = threadIdx.x & 31, grp = threadIdx.x >> 5;
-  const i64 rows = (i64)taps * Co * ci_blocks;
-  const i64 slice = (i64)taps * CoP * CiP;
-  for (i64 b = blockIdx.x; b < rows; b += gridDim.x) {
-    const int cb = (int)(b % ci_blocks);
-    const i64 r = b / ci_blocks;
-    const int co = (int)(r % Co), t = (int)(r / Co);
-    const int ci = cb * 32 + lane32;
-    float s = 0.f;
-    if (ci < Ci) {
-      const float *p = partial + ((i64)t * CoP + co) * CiP + ci;
-      for (int k = grp; k < splits; k += 8) s += p[k * slice];
-    }
-    red[grp][lane32] = s;
-    __syncthreads();
-    if (grp == 0 && ci < Ci) {
-      float tot = red[0][lane32];
-#pragma unroll
-      for (int g = 1; g < 8; ++g) tot += red[g][lane32];
-      grad[((i64)ci * Co + co) * taps_total + tap_base + t] = tot;
-    }
-    __syncthreads();
-  }
-}
-
-// Same reduction for layers with many outputs and few split slices: a workgroup owns a
-// 32(ci) x 8(co) x taps box, reads it with 128-byte coalesced rows, transposes through LDS and
-// writes runs of 8*taps consecutive floats of the reference layout.
-__global__ __launch_bounds__(256) void wgrad_reduce_tile_kernel(const float *__restrict__ partial,
-                                                                float *__restrict__ grad, int splits, int taps,
-                                                                int CoP, int CiP, int Co, int Ci, int taps_total,
-                                                                int tap_base) {
-  __shared__ float tile[32][8 * 9 + 1];
-  const int lane32 = threadIdx.x & 31, grp = threadIdx.x >> 5;
-  const int ci0 = blockIdx.x * 32, co0 = blockIdx.y * 8;
-  const int ci = ci0 + lane32, co = co0 + grp;
-  const i64 slice = (i64)taps * CoP * CiP;
-  for (int t = 0; t < taps; ++t) {
-    float s = 0.f;
-    if (ci < Ci && co < Co) {
-      const float *p = partial + ((i64)t * CoP + co) * CiP + ci;
-      for (int k = 0; k < splits; ++k) s += p[k * slice];
-    }
-    tile[lane32][grp * taps + t] = s;
-  }
-  __syncthreads();
-  const int run = 8 * taps;
-  for (int idx = threadIdx.x; idx < 32 * run; idx += 256) {
-    const int cl = idx / run, rem = idx - cl * run;
-    const int col = rem / taps, t = rem - col * taps;
-    if (ci0 + cl < Ci && co0 + col < Co)
-      grad[((i64)(ci0 + cl) * Co + co0 + col) * taps_total + tap_base + t] = tile[cl][rem];
-  }
-}
-
-// ---------------------------------------------------------------------------
 // Weight packing and layout conversion.
 // ---------------------------------------------------------------------------
 // w_ref [Ci][Co][K][K] fp32 ->
 //   fwd [tap][CoP][CiP] bf16 (tap = kh*K+kw), zero padded
 //   bwd [tap][CiP][CoP] bf16 with flipped taps for K=3 (data gradient as a forward conv over dZ);
 //       unflipped for the transposed-conv phases (K=2, taps are the (i,j) phases)
+// A workgroup moves a 32(ci) x 32(co) x taps box: contiguous reads of the reference layout into
+// LDS, then 64-byte runs along ci (fwd) and along co (bwd).
 __global__ __launch_bounds__(256) void pack_weights_kernel(const float *__restrict__ w, bf16_t *__restrict__ fwd,
                                                            bf16_t *__restrict__ bwd, int Ci, int Co, int CiP,
                                                            int CoP, int K) {
-  const int taps = K * K;
-  const i64 total = (i64)taps * CoP * CiP;
-  for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (i64)gridDim.x * blockDim.x) {
-    const int ci = (int)(i % CiP);
-    const i64 r = i / CiP;
-    const int co = (int)(r % CoP), t = (int)(r / CoP);
-    float v = 0.f;
-    if (ci < Ci && co < Co) v = w[((i64)ci * Co + co) * taps + t];
-    const bf16_t hv = (bf16_t)f32_to_bf16(v);
-    if (fwd) fwd[i] = hv;
-    if (bwd) {
+  __shared__ float tile[32 * (32 * 9 + 1)];
+  const int taps = K * K, run = 32 * taps, pitch = run + 1;
+  const int ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32;
+  for (int idx = threadIdx.x; idx < 32 * run; idx += 256) {
+    const int cl = idx / run, rem = idx - cl * run;
+    const int ci = ci0 + cl, co = co0 + rem / taps;
+    tile[cl * pitch + rem] = (ci < Ci && co < Co) ? w[((i64)ci * Co + co0) * taps + rem] : 0.f;
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < taps * 1024; idx += 256) {
+    const int a = idx & 31, b = (idx >> 5) & 31, t = idx >> 10;
+    if (fwd)  // a = ci (fastest), b = co
+      fwd[((i64)t * CoP + co0 + b) * CiP + ci0 + a] = (bf16_t)f32_to_bf16(tile[a * pitch + b * taps + t]);
+    if (bwd) {  // a = co (fastest), b = ci
       const int tb = (K == 3) ? (taps - 1 - t) : t;
-      bwd[((i64)tb * CiP + ci) * CoP + co] = hv;
+      bwd[((i64)tb * CiP + ci0 + b) * CoP + co0 + a] = (bf16_t)f32_to_bf16(tile[b * pitch + a * taps + t]);
     }
   }
 }
@@ -604,9 +393,8 @@ int unet_pack_weights_bf16(const float *w_ref, uint16_t *w_fwd, uint16_t *w_bwd,
   UNET_REQUIRE(w_ref && (w_fwd || w_bwd), "unet_pack_weights_bf16: NULL pointer");
   UNET_REQUIRE(Ci > 0 && Co > 0 && CiP >= Ci && CoP >= Co && (K == 3 || K == 2) && CiP % 32 == 0 && CoP % 32 == 0,
                "unet_pack_weights_bf16: need K in {2,3} and padded channel counts that are multiples of 32");
-  const i64 total = (i64)K * K * CoP * CiP;
-  hipLaunchKernelGGL(pack_weights_kernel, dim3(ew_grid(total)), dim3(256), 0, as_stream(s), w_ref, w_fwd, w_bwd, Ci,
-                     Co, CiP, CoP, K);
+  hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)(CiP / 32), (unsigned)(CoP / 32)), dim3(256), 0, as_stream(s),
+                     w_ref, w_fwd, w_bwd, Ci, Co, CiP, CoP, K);
   UNET_LAUNCH_CHECK("pack_weights_kernel");
   return UNET_OK;
 }
@@ -711,92 +499,6 @@ int unet_tconv2x2_dgrad_bf16(const uint16_t *dy, int dy_ld, const uint16_t *w_pa
   a.out_phases = 1; a.k_phases = 4;
   a.wt_phase_stride = (i64)CiP * CoP;
   return launch_conv_any(1, a, as_stream(s));
-}
-
-static int run_wgrad(int taps, const WgradArgs &base, float *grad, int Ci, int Co, int taps_total, int tap_base,
-                     hipStream_t s) {
-  WgradArgs a = base;
-  a.chunksX = (a.W + 15) / 16;
-  a.chunksY = (a.H + 7) / 8;
-  a.total_chunks = a.N * a.chunksX * a.chunksY;
-  const int tiles = (a.CoP / 64) * (a.CiP / 64);
-  int splits = (512 + tiles - 1) / tiles;
-  if (splits > a.total_chunks) splits = a.total_chunks;
-  if (splits < 1) splits = 1;
-  a.chunks_per_split = (a.total_chunks + splits - 1) / splits;
-  splits = (a.total_chunks + a.chunks_per_split - 1) / a.chunks_per_split;
-  void *ws;
-  int rc = unet_workspace(&ws, sizeof(float) * (size_t)splits * taps * a.CoP * a.CiP);
-  if (rc) return rc;
-  a.partial = (float *)ws;
-  const size_t lds = (size_t)128 * WP + (size_t)(taps == 9 ? 180 : 128) * WP;
-  static bool attr_set[2][64] = {};
-  int dev = 0;
-  UNET_HIP_TRY(hipGetDevice(&dev));
-  if (!attr_set[taps == 9][dev & 63]) {
-    if (taps == 9)
-      UNET_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&wgrad_mfma_kernel<9>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    else
-      UNET_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&wgrad_mfma_kernel<1>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set[taps == 9][dev & 63] = true;
-  }
-  dim3 grid((unsigned)splits, (unsigned)(a.CoP / 64), (unsigned)(a.CiP / 64));
-  if (taps == 9)
-    hipLaunchKernelGGL(wgrad_mfma_kernel<9>, grid, dim3(256), lds, s, a);
-  else
-    hipLaunchKernelGGL(wgrad_mfma_kernel<1>, grid, dim3(256), lds, s, a);
-  UNET_LAUNCH_CHECK("wgrad_mfma_kernel");
-  const i64 boxes = (i64)((Ci + 31) / 32) * ((Co + 7) / 8);
-  if (boxes >= 512 && splits <= 16) {
-    hipLaunchKernelGGL(wgrad_reduce_tile_kernel, dim3((unsigned)((Ci + 31) / 32), (unsigned)((Co + 7) / 8)), dim3(256), 0,
-                       s, (const float *)ws, grad, splits, taps, a.CoP, a.CiP, Co, Ci, taps_total, tap_base);
-  } else {
-    const i64 reduce_rows = (i64)taps * Co * ((Ci + 31) / 32);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(reduce_rows < 65536 ? reduce_rows : 65536)), dim3(256), 0,
-                       s, (const float *)ws, grad, splits, taps, a.CoP, a.CiP, Co, Ci, taps_total, tap_base);
-  }
-  UNET_LAUNCH_CHECK("wgrad_reduce_kernel");
-  return UNET_OK;
-}
-
-// grad_w [Ci][Co][3][3] fp32 (reference layout, overwritten)
-int unet_conv3x3_wgrad_bf16(const uint16_t *dz, int dz_ld, const uint16_t *x, int x_ld, float *grad_w, int N, int H,
-                            int W, int CiP, int CoP, int Ci, int Co, unet_stream_t s) {
-  UNET_REQUIRE(dz && x && grad_w, "unet_conv3x3_wgrad_bf16: NULL pointer");
-  UNET_REQUIRE(N > 0 && H > 0 && W > 0 && Ci > 0 && Co > 0 && Ci <= CiP && Co <= CoP,
-               "unet_conv3x3_wgrad_bf16: bad sizes");
-  UNET_REQUIRE(CiP % 8 == 0 && CoP % 8 == 0 && dz_ld >= CoP && x_ld >= CiP && dz_ld % 8 == 0 && x_ld % 8 == 0,
-               "unet_conv3x3_wgrad_bf16: padded channel counts and pixel strides must be multiples of 8");
-  WgradArgs a{};
-  a.dz = dz; a.x = x; a.N = N; a.H = H; a.W = W; a.Hz = H; a.Wz = W; a.dz_ld = dz_ld; a.x_ld = x_ld;
-  a.CoP = (CoP + 63) / 64 * 64; a.CiP = (CiP + 63) / 64 * 64; a.z_c = CoP; a.x_c = CiP;
-  a.dz_s = 1; a.dz_oy = a.dz_ox = 0;
-  ProfScope prof(PROF_CONV_WGRAD_BF16, 2.0 * N * H * W * (double)CiP * CoP * 9, 2.0 * N * H * W * ((double)CiP + CoP),
-                 as_stream(s));
-  return run_wgrad(9, a, grad_w, Ci, Co, 9, 0, as_stream(s));
-}
-
-// grad_w [Ci][Co][2][2] fp32 (overwritten); x = the transposed conv's input, dy its output gradient
-int unet_tconv2x2_wgrad_bf16(const uint16_t *dy, int dy_ld, const uint16_t *x, int x_ld, float *grad_w, int N,
-                             int H_in, int W_in, int CiP, int CoP, int Ci, int Co, unet_stream_t s) {
-  UNET_REQUIRE(dy && x && grad_w, "unet_tconv2x2_wgrad_bf16: NULL pointer");
-  UNET_REQUIRE(N > 0 && H_in > 0 && W_in > 0 && Ci > 0 && Co > 0 && Ci <= CiP && Co <= CoP,
-               "unet_tconv2x2_wgrad_bf16: bad sizes");
-  UNET_REQUIRE(CiP % 8 == 0 && CoP % 8 == 0 && dy_ld >= CoP && x_ld >= CiP && dy_ld % 8 == 0 && x_ld % 8 == 0,
-               "unet_tconv2x2_wgrad_bf16: padded channel counts and pixel strides must be multiples of 8");
-  ProfScope prof(PROF_TCONV_BF16, 2.0 * N * H_in * W_in * 4.0 * CiP * CoP,
-                 2.0 * N * H_in * W_in * ((double)CiP + 4.0 * CoP), as_stream(s));
-  for (int ph = 0; ph < 4; ++ph) {
-    WgradArgs a{};
-    a.dz = dy; a.x = x; a.N = N; a.H = H_in; a.W = W_in; a.Hz = 2 * H_in; a.Wz = 2 * W_in;
-    a.dz_ld = dy_ld; a.x_ld = x_ld; a.CoP = (CoP + 63) / 64 * 64; a.CiP = (CiP + 63) / 64 * 64;
-    a.z_c = CoP; a.x_c = CiP; a.dz_s = 2; a.dz_oy = ph >> 1; a.dz_ox = ph & 1;
-    int rc = run_wgrad(1, a, grad_w, Ci, Co, 4, ph, as_stream(s));
-    if (rc) return rc;
-  }
-  return UNET_OK;
 }
 
 }  // extern "C"

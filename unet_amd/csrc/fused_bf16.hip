@@ -127,9 +127,9 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const bf16_t *__restrict__ 
     ca[j] = c.a;
     cb[j] = c.b;
   }
-  for (i64 p = (i64)blockIdx.x * PL + pl; p < pixels; p += (i64)gridDim.x * PL) {
+  auto apply = [&](const uint4 &in) {
     float v[8];
-    unpack8(*reinterpret_cast<const uint4 *>(z + p * z_ld + cg * 8), v);
+    unpack8(in, v);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       float t = fmaf(ca[j], v[j], cb[j]);
@@ -137,8 +137,20 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const bf16_t *__restrict__ 
       if (ACT == 1) t = 1.0f / (1.0f + __expf(-t));
       v[j] = t;
     }
-    *reinterpret_cast<uint4 *>(y + p * y_ld + cg * 8) = pack8(v);
+    return pack8(v);
+  };
+  const i64 stride = (i64)gridDim.x * PL;
+  i64 p = (i64)blockIdx.x * PL + pl;
+  // four pixels per trip: four independent 16-byte loads in flight per lane
+  for (; p + 3 * stride < pixels; p += 4 * stride) {
+    uint4 in[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) in[u] = *reinterpret_cast<const uint4 *>(z + (p + u * stride) * z_ld + cg * 8);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) *reinterpret_cast<uint4 *>(y + (p + u * stride) * y_ld + cg * 8) = apply(in[u]);
   }
+  for (; p < pixels; p += stride)
+    *reinterpret_cast<uint4 *>(y + p * y_ld + cg * 8) = apply(*reinterpret_cast<const uint4 *>(z + p * z_ld + cg * 8));
 }
 
 // ---- backward -------------------------------------------------------------------
@@ -173,23 +185,43 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const bf16_t *__rest
 #pragma unroll
     for (int j = 0; j < 8; ++j) c[j] = cf[cg * 8 + j];
     const i64 p0 = (i64)blockIdx.x * ppb, p1 = min(pixels, p0 + ppb);
-    for (i64 p = p0 + pl; p < p1; p += PL) {
+    auto accumulate = [&](const uint4 &r1, const uint4 &r2, const uint4 &rz) {
       float g[8], zv[8];
-      unpack8(*reinterpret_cast<const uint4 *>(dy1 + p * ld1 + cg * 8), g);
+      unpack8(r1, g);
       if (dy2) {
         float g2[8];
-        unpack8(*reinterpret_cast<const uint4 *>(dy2 + p * ld2 + cg * 8), g2);
+        unpack8(r2, g2);
 #pragma unroll
         for (int j = 0; j < 8; ++j) g[j] += g2[j];
       }
-      unpack8(*reinterpret_cast<const uint4 *>(z + p * z_ld + cg * 8), zv);
+      unpack8(rz, zv);
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const float gj = act_grad<ACT>(g[j], fmaf(c[j].a, zv[j], c[j].b));
         s[2 * j] += gj * ((zv[j] - c[j].mean) * c[j].invb);
         s[2 * j + 1] += gj;
       }
+    };
+    const uint4 zero4 = make_uint4(0, 0, 0, 0);
+    i64 p = p0 + pl;
+    // two pixels per trip keep four to six independent 16-byte loads in flight per lane
+    for (; p + PL < p1; p += 2 * PL) {
+      const uint4 a1 = *reinterpret_cast<const uint4 *>(dy1 + p * ld1 + cg * 8);
+      const uint4 b1 = *reinterpret_cast<const uint4 *>(dy1 + (p + PL) * ld1 + cg * 8);
+      const uint4 az = *reinterpret_cast<const uint4 *>(z + p * z_ld + cg * 8);
+      const uint4 bz = *reinterpret_cast<const uint4 *>(z + (p + PL) * z_ld + cg * 8);
+      uint4 a2 = zero4, b2 = zero4;
+      if (dy2) {
+        a2 = *reinterpret_cast<const uint4 *>(dy2 + p * ld2 + cg * 8);
+        b2 = *reinterpret_cast<const uint4 *>(dy2 + (p + PL) * ld2 + cg * 8);
+      }
+      accumulate(a1, a2, az);
+      accumulate(b1, b2, bz);
     }
+    if (p < p1)
+      accumulate(*reinterpret_cast<const uint4 *>(dy1 + p * ld1 + cg * 8),
+                 dy2 ? *reinterpret_cast<const uint4 *>(dy2 + p * ld2 + cg * 8) : zero4,
+                 *reinterpret_cast<const uint4 *>(z + p * z_ld + cg * 8));
 #pragma unroll
     for (int j = 0; j < 16; ++j) red[(pl * CG + cg) * 16 + j] = s[j];
   }
@@ -251,16 +283,16 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16_t *__restr
       b[j] = cb[cg * 8 + j];
     }
     const i64 p0 = (i64)blockIdx.x * ppb, p1 = min(pixels, p0 + ppb);
-    for (i64 p = p0 + pl; p < p1; p += PL) {
+    auto apply = [&](const uint4 &r1, const uint4 &r2, const uint4 &rz) {
       float g[8], zv[8], o[8];
-      unpack8(*reinterpret_cast<const uint4 *>(dy1 + p * ld1 + cg * 8), g);
+      unpack8(r1, g);
       if (dy2) {
         float g2[8];
-        unpack8(*reinterpret_cast<const uint4 *>(dy2 + p * ld2 + cg * 8), g2);
+        unpack8(r2, g2);
 #pragma unroll
         for (int j = 0; j < 8; ++j) g[j] += g2[j];
       }
-      unpack8(*reinterpret_cast<const uint4 *>(z + p * z_ld + cg * 8), zv);
+      unpack8(rz, zv);
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const float gj = act_grad<ACT>(g[j], fmaf(c[j].a, zv[j], c[j].b));
@@ -268,12 +300,32 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16_t *__restr
         o[j] = b[j].c0 * (gj - b[j].k1 - xh * b[j].k2);
       }
       const uint4 packed = pack8(o);
-      *reinterpret_cast<uint4 *>(dz + p * dz_ld + cg * 8) = packed;
       float r[8];
       unpack8(packed, r);  // the bias gradient sums what the weight-gradient kernels will read
 #pragma unroll
       for (int j = 0; j < 8; ++j) s[j] += r[j];
+      return packed;
+    };
+    const uint4 zero4 = make_uint4(0, 0, 0, 0);
+    i64 p = p0 + pl;
+    for (; p + PL < p1; p += 2 * PL) {
+      const uint4 a1 = *reinterpret_cast<const uint4 *>(dy1 + p * ld1 + cg * 8);
+      const uint4 b1 = *reinterpret_cast<const uint4 *>(dy1 + (p + PL) * ld1 + cg * 8);
+      const uint4 az = *reinterpret_cast<const uint4 *>(z + p * z_ld + cg * 8);
+      const uint4 bz = *reinterpret_cast<const uint4 *>(z + (p + PL) * z_ld + cg * 8);
+      uint4 a2 = zero4, b2 = zero4;
+      if (dy2) {
+        a2 = *reinterpret_cast<const uint4 *>(dy2 + p * ld2 + cg * 8);
+        b2 = *reinterpret_cast<const uint4 *>(dy2 + (p + PL) * ld2 + cg * 8);
+      }
+      *reinterpret_cast<uint4 *>(dz + p * dz_ld + cg * 8) = apply(a1, a2, az);
+      *reinterpret_cast<uint4 *>(dz + (p + PL) * dz_ld + cg * 8) = apply(b1, b2, bz);
     }
+    if (p < p1)
+      *reinterpret_cast<uint4 *>(dz + p * dz_ld + cg * 8) =
+          apply(*reinterpret_cast<const uint4 *>(dy1 + p * ld1 + cg * 8),
+                dy2 ? *reinterpret_cast<const uint4 *>(dy2 + p * ld2 + cg * 8) : zero4,
+                *reinterpret_cast<const uint4 *>(z + p * z_ld + cg * 8));
 #pragma unroll
     for (int j = 0; j < 8; ++j) red[(pl * CG + cg) * 8 + j] = s[j];
   }
@@ -432,7 +484,7 @@ int unet_bn_act_bf16(const uint16_t *z, int z_ld, uint16_t *y, int y_ld, const f
   const int CG = CoP / 8, PL = 256 / CG;
   const dim3 grid(ew_grid((pixels + PL - 1) / PL * 256 / 4));
   const ChanFwd *cf = reinterpret_cast<const ChanFwd *>(coef);
-  ProfScope prof(PROF_BN_RELU_BF16, 0, 4.0 * pixels * CoP, as_stream(s));
+  ProfScope prof(PROF_BN_ACT_BF16, 0, 4.0 * pixels * CoP, as_stream(s));
   if (act == 0)
     hipLaunchKernelGGL(bn_act_kernel<0>, grid, dim3(256), 0, as_stream(s), z, z_ld, y, y_ld, cf, CG, PL, (i64)pixels);
   else if (act == 1)
@@ -464,18 +516,24 @@ int unet_bn_act_backward_bf16(const uint16_t *dy1, int ld1, const uint16_t *dy2,
   const ChanFwd *cf = reinterpret_cast<const ChanFwd *>(coef);
   ChanBwd *cb = reinterpret_cast<ChanBwd *>(cbf);
   const size_t lds1 = sizeof(float) * (size_t)pl.PL * pl.CG * 16, lds2 = sizeof(float) * (size_t)pl.PL * pl.CG * 8;
-  ProfScope prof(PROF_BN_RELU_BF16, 0, 2.0 * pixels * CoP * (dy2 ? 7.0 : 5.0), as_stream(s));
+  const double elems = (double)pixels * CoP;
 #define BWD_LAUNCH(ACT_)                                                                                            \
   do {                                                                                                              \
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel<ACT_>, dim3(pl.blocks), dim3(256), lds1, as_stream(s), dy1, ld1, dy2,  \
-                       ld2, z, z_ld, cf, pl.CG, pl.PL, (i64)pixels, pl.ppb, partial, CoP);                          \
+    {                                                                                                               \
+      ProfScope prof(PROF_BN_BWD_REDUCE_BF16, 0, 2.0 * elems * (dy2 ? 3.0 : 2.0), as_stream(s));                    \
+      hipLaunchKernelGGL(bn_bwd_reduce_kernel<ACT_>, dim3(pl.blocks), dim3(256), lds1, as_stream(s), dy1, ld1,     \
+                         dy2, ld2, z, z_ld, cf, pl.CG, pl.PL, (i64)pixels, pl.ppb, partial, CoP);                   \
+    }                                                                                                               \
     UNET_LAUNCH_CHECK("bn_bwd_reduce_kernel");                                                                      \
     hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(cdiv_u(CoP, 4)), dim3(256), 0, as_stream(s),                    \
                        (const float *)partial, pl.blocks, C, CoP, (float)pixels, gamma_beta, cf, grad_gb, cb);      \
     UNET_LAUNCH_CHECK("bn_finalize_bwd_kernel");                                                                    \
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<ACT_>, dim3(pl.blocks), dim3(256), lds2, as_stream(s), dy1, ld1, dy2,   \
-                       ld2, z, z_ld, cf, (const ChanBwd *)cb, dz, dz_ld, pl.CG, pl.PL, (i64)pixels, pl.ppb,         \
-                       bias_part, CoP);                                                                             \
+    {                                                                                                               \
+      ProfScope prof(PROF_BN_BWD_APPLY_BF16, 0, 2.0 * elems * (dy2 ? 4.0 : 3.0), as_stream(s));                     \
+      hipLaunchKernelGGL(bn_bwd_apply_kernel<ACT_>, dim3(pl.blocks), dim3(256), lds2, as_stream(s), dy1, ld1,      \
+                         dy2, ld2, z, z_ld, cf, (const ChanBwd *)cb, dz, dz_ld, pl.CG, pl.PL, (i64)pixels, pl.ppb,  \
+                         bias_part, CoP);                                                                           \
+    }                                                                                                               \
     UNET_LAUNCH_CHECK("bn_bwd_apply_kernel");                                                                       \
   } while (0)
   if (act == 0) BWD_LAUNCH(0);

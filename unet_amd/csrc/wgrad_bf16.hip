@@ -1,0 +1,325 @@
+// bf16 weight gradient of the 3x3 convolution and of the 2x2 transposed convolution on the gfx950
+// matrix cores.
+//
+// dW[tap][co][ci] = sum_pixel dZ[pixel][co] * X[pixel + off(tap)][ci]
+//   - the reduction runs over pixels, which is the strided dimension of both NHWC operands;
+//     ds_read_b64_tr_b16 (the transposing LDS read of gfx950) delivers the [pixel][channel] LDS
+//     tiles as K-contiguous MFMA fragments;
+//   - a workgroup owns a 64(co) x 64(ci) block of all filter taps and a slice of the pixels
+//     (split-K); partial blocks go to a workspace and a second kernel adds the slices in a fixed
+//     order (deterministic) while converting to the reference's [C_in][C_out][k][k] fp32 layout.
+// This file is compiled with -mllvm -amdgpu-mfma-vgpr-form: the 9 accumulator tiles of a wave stay
+// in ordinary vector registers.  Without it the compiler copies all 144 accumulator registers
+// between the two halves of the register file on every pass of the pixel loop.
+#include "bf16_util.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------
+// Weight gradient.
+// ---------------------------------------------------------------------------
+struct WgradArgs {
+  const bf16_t *dz;  // [N][Hz][Wz][dz_ld], CoP channels used
+  const bf16_t *x;   // [N][H][W][x_ld], CiP channels used
+  float *partial;    // [splits][TAPS][CoP][CiP] fp32
+  int N, H, W;       // logical pixel grid = x image size
+  int Hz, Wz;        // dz image size
+  int dz_ld, x_ld, CoP, CiP;  // partial-buffer dims (multiples of 64)
+  int z_c, x_c;               // channels present in dz / x (multiples of 8)
+  int dz_s, dz_oy, dz_ox;  // dz pixel of logical (y,x): (y*dz_s+dz_oy, x*dz_s+dz_ox)
+  int chunksX, chunksY;    // 8x16 pixel chunks per image
+  int chunks_per_split, total_chunks;
+};
+
+constexpr int WP = 192;  // LDS row pitch (bytes) of a 64-channel pixel row: 4 rows x 64 B fall in 4 distinct bank quarters
+
+// The kernel is written to spend its issue slots on MFMAs, not on address arithmetic:
+//   - operands are fetched with buffer loads: one descriptor per image, a 32-bit per-lane byte offset,
+//     and out-of-range pixels / channels get an offset beyond the descriptor, which the hardware
+//     answers with zeros (no branches, no selects);
+//   - the per-lane offsets inside a chunk are computed once; a chunk adds one scalar;
+//   - the accumulator tiles stay in ordinary vector registers (see the note on compile flags above).
+template <int TAPS>
+__global__ __launch_bounds__(256, 1) void wgrad_mfma_kernel(const WgradArgs a) {
+  constexpr int XR = (TAPS == 9) ? 10 : 8, XC = (TAPS == 9) ? 18 : 16;
+  constexpr int XPIX = XR * XC, ZPIX = 128;
+  constexpr int XCH = XPIX * 8, XI = (XCH + 255) / 256;
+  constexpr int ZCH = ZPIX * 8, ZI = ZCH / 256;
+  constexpr unsigned OOB = 0xffffffffu;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  unsigned char *ldsZ = lds, *ldsX = lds + ZPIX * WP;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int co0 = blockIdx.y * 64, ci0 = blockIdx.z * 64, split = blockIdx.x;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  f32x16 acc[TAPS];
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  const int grp = lane >> 4, li = lane & 15, q = li >> 2, p = li & 3, h = grp >> 1;
+  const int z_lane = (8 * h + q) * WP + (wm * 32 + 16 * (grp & 1) + 4 * p) * 2;
+  const int x_lane = (8 * h + q) * WP + (wn * 32 + 16 * (grp & 1) + 4 * p) * 2;
+
+  const int c_begin = split * a.chunks_per_split;
+  const int c_end = min(a.total_chunks, c_begin + a.chunks_per_split);
+  const int per_img = a.chunksX * a.chunksY;
+
+  // per-lane geometry of the staged 16-byte pieces, fixed for the whole kernel
+  const int part = tid & 7;
+  const bool x_ch_ok = ci0 + part * 8 < a.x_c, z_ch_ok = co0 + part * 8 < a.z_c;
+  int x_py[XI], x_px[XI];
+  unsigned x_rel[XI], z_rel[ZI];
+  int z_py[ZI], z_px[ZI];
+#pragma unroll
+  for (int i = 0; i < XI; ++i) {
+    const int pix = (tid + 256 * i) >> 3;
+    x_py[i] = pix / XC - (TAPS == 9);
+    x_px[i] = pix - (pix / XC) * XC - (TAPS == 9);
+    if (!(XCH % 256 == 0 || tid + 256 * i < XCH) || !x_ch_ok) x_py[i] = -100000;  // never in range
+    x_rel[i] = (unsigned)(((x_py[i] * a.W + x_px[i]) * a.x_ld + ci0 + part * 8) * 2);
+  }
+#pragma unroll
+  for (int i = 0; i < ZI; ++i) {
+    const int pix = (tid + 256 * i) >> 3;
+    z_py[i] = z_ch_ok ? (pix >> 4) : -100000;
+    z_px[i] = pix & 15;
+    z_rel[i] = (unsigned)((((z_py[i] * a.dz_s + a.dz_oy) * a.Wz + z_px[i] * a.dz_s + a.dz_ox) * a.dz_ld + co0 + part * 8) * 2);
+  }
+  const unsigned x_img_bytes = (unsigned)a.H * a.W * a.x_ld * 2u, z_img_bytes = (unsigned)a.Hz * a.Wz * a.dz_ld * 2u;
+  const int st_off = (tid >> 3) * WP + (tid & 7) * 16;  // piece i sits 32 pixel rows further
+
+  i32x4 xr[XI], zr[ZI];
+  auto load_chunk = [&](int chunk) {
+    const int n = chunk / per_img, r = chunk - n * per_img;
+    const int cy = r / a.chunksX;
+    const int y0 = cy * 8, x0 = (r - cy * a.chunksX) * 16;
+    const auto xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(a.x) + (i64)n * a.H * a.W * a.x_ld, 0,
+                                                       x_img_bytes, 0x00020000);
+    const auto zrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(a.dz) + (i64)n * a.Hz * a.Wz * a.dz_ld, 0,
+                                                       z_img_bytes, 0x00020000);
+    const unsigned x_org = (unsigned)((y0 * a.W + x0) * a.x_ld * 2);
+    const unsigned z_org = (unsigned)((y0 * a.dz_s * a.Wz + x0 * a.dz_s) * a.dz_ld * 2);
+#pragma unroll
+    for (int i = 0; i < XI; ++i) {
+      const bool ok = (unsigned)(y0 + x_py[i]) < (unsigned)a.H && (unsigned)(x0 + x_px[i]) < (unsigned)a.W;
+      xr[i] = __builtin_amdgcn_raw_buffer_load_b128(xrs, ok ? x_org + x_rel[i] : OOB, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < ZI; ++i) {
+      const bool ok = (unsigned)(y0 + z_py[i]) < (unsigned)a.H && (unsigned)(x0 + z_px[i]) < (unsigned)a.W;
+      zr[i] = __builtin_amdgcn_raw_buffer_load_b128(zrs, ok ? z_org + z_rel[i] : OOB, 0, 0);
+    }
+  };
+  auto store_chunk = [&]() {
+#pragma unroll
+    for (int i = 0; i < XI; ++i)
+      if (XCH % 256 == 0 || tid + 256 * i < XCH) *reinterpret_cast<i32x4 *>(ldsX + st_off + i * 32 * WP) = xr[i];
+#pragma unroll
+    for (int i = 0; i < ZI; ++i) *reinterpret_cast<i32x4 *>(ldsZ + st_off + i * 32 * WP) = zr[i];
+  };
+
+  load_chunk(c_begin);
+  store_chunk();
+  __syncthreads();
+  for (int chunk = c_begin; chunk < c_end; ++chunk) {
+    if (chunk + 1 < c_end) load_chunk(chunk + 1);
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      const unsigned char *zp = ldsZ + ks * 16 * WP + z_lane;
+      const bf16x8 af = tr_read_pair(zp, zp + 4 * WP);
+#pragma unroll
+      for (int t = 0; t < TAPS; ++t) {
+        const int kh = (TAPS == 9) ? t / 3 : 0, kw = (TAPS == 9) ? t % 3 : 0;
+        const unsigned char *xp = ldsX + ((ks + kh) * XC + kw) * WP + x_lane;
+        const bf16x8 bfr = tr_read_pair(xp, xp + 4 * WP);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, acc[t], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+    if (chunk + 1 < c_end) {
+      store_chunk();
+      __syncthreads();
+    }
+  }
+  // partial[split][tap][co][ci] through one descriptor per split slice and 32-bit offsets
+  const auto prs = __builtin_amdgcn_make_buffer_rsrc(a.partial + (i64)split * TAPS * a.CoP * a.CiP, 0,
+                                                     (unsigned)TAPS * a.CoP * a.CiP * 4u, 0x00020000);
+  const unsigned row_bytes = (unsigned)a.CiP * 4u;
+  unsigned off = ((unsigned)(co0 + wm * 32 + 4 * (lane >> 5)) * a.CiP + ci0 + wn * 32 + (lane & 31)) * 4u;
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t) {
+    unsigned o = off;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {  // register r holds row (r&3) + 8*(r>>2) (+ 4*(lane>>5))
+      const float v = acc[t][r];
+      __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(v), prs, o, 0, 0);
+      o += ((r & 3) == 3) ? 5 * row_bytes : row_bytes;
+    }
+    off += (unsigned)a.CoP * row_bytes;
+  }
+}
+
+// grad[(ci*Co + co)*taps_total + tap_base + t] = sum_split partial[split][t][co][ci]
+// A workgroup owns 32 consecutive ci of one (t, co) row; its 8 groups of 32 lanes each add every
+// eighth split slice (128-byte coalesced reads), then the 8 partial sums are added in a fixed order.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restrict__ partial,
+                                                           float *__restrict__ grad, int splits, int taps,
+                                                           int CoP, int CiP, int Co, int Ci, int taps_total,
+                                                           int tap_base) {
+  __shared__ float red[8][32];
+  const int ci_blocks = (Ci + 31) / 32;
+  const int lane32 = threadIdx.x & 31, grp = threadIdx.x >> 5;
+  const i64 rows = (i64)taps * Co * ci_blocks;
+  const i64 slice = (i64)taps * CoP * CiP;
+  for (i64 b = blockIdx.x; b < rows; b += gridDim.x) {
+    const int cb = (int)(b % ci_blocks);
+    const i64 r = b / ci_blocks;
+    const int co = (int)(r % Co), t = (int)(r / Co);
+    const int ci = cb * 32 + lane32;
+    float s = 0.f;
+    if (ci < Ci) {
+      const float *p = partial + ((i64)t * CoP + co) * CiP + ci;
+      for (int k = grp; k < splits; k += 8) s += p[k * slice];
+    }
+    red[grp][lane32] = s;
+    __syncthreads();
+    if (grp == 0 && ci < Ci) {
+      float tot = red[0][lane32];
+#pragma unroll
+      for (int g = 1; g < 8; ++g) tot += red[g][lane32];
+      grad[((i64)ci * Co + co) * taps_total + tap_base + t] = tot;
+    }
+    __syncthreads();
+  }
+}
+
+// Same reduction for layers with many outputs and few split slices: a workgroup owns a
+// 32(ci) x 8(co) x taps box, reads it with 128-byte coalesced rows, transposes through LDS and
+// writes runs of 8*taps consecutive floats of the reference layout.
+__global__ __launch_bounds__(256) void wgrad_reduce_tile_kernel(const float *__restrict__ partial,
+                                                                float *__restrict__ grad, int splits, int taps,
+                                                                int CoP, int CiP, int Co, int Ci, int taps_total,
+                                                                int tap_base) {
+  __shared__ float tile[32][8 * 9 + 1];
+  const int lane32 = threadIdx.x & 31, grp = threadIdx.x >> 5;
+  const int ci0 = blockIdx.x * 32, co0 = blockIdx.y * 8;
+  const int ci = ci0 + lane32, co = co0 + grp;
+  const i64 slice = (i64)taps * CoP * CiP;
+  for (int t = 0; t < taps; ++t) {
+    float s = 0.f;
+    if (ci < Ci && co < Co) {
+      const float *p = partial + ((i64)t * CoP + co) * CiP + ci;
+      for (int k = 0; k < splits; ++k) s += p[k * slice];
+    }
+    tile[lane32][grp * taps + t] = s;
+  }
+  __syncthreads();
+  const int run = 8 * taps;
+  for (int idx = threadIdx.x; idx < 32 * run; idx += 256) {
+    const int cl = idx / run, rem = idx - cl * run;
+    const int col = rem / taps, t = rem - col * taps;
+    if (ci0 + cl < Ci && co0 + col < Co)
+      grad[((i64)(ci0 + cl) * Co + co0 + col) * taps_total + tap_base + t] = tile[cl][rem];
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+static int run_wgrad(int taps, const WgradArgs &base, float *grad, int Ci, int Co, int taps_total, int tap_base,
+                     double flops, hipStream_t s) {
+  WgradArgs a = base;
+  a.chunksX = (a.W + 15) / 16;
+  a.chunksY = (a.H + 7) / 8;
+  a.total_chunks = a.N * a.chunksX * a.chunksY;
+  const int tiles = (a.CoP / 64) * (a.CiP / 64);
+  // two workgroups per CU's worth of blocks: small enough slices that a CU lent to a concurrent
+  // collective costs little, large enough that the partial sums stay a minor part of the traffic
+  int splits = (512 + tiles - 1) / tiles;
+  if (splits > a.total_chunks) splits = a.total_chunks;
+  if (splits < 1) splits = 1;
+  a.chunks_per_split = (a.total_chunks + splits - 1) / splits;
+  splits = (a.total_chunks + a.chunks_per_split - 1) / a.chunks_per_split;
+  void *ws;
+  int rc = unet_workspace(&ws, sizeof(float) * (size_t)splits * taps * a.CoP * a.CiP);
+  if (rc) return rc;
+  a.partial = (float *)ws;
+  const size_t lds = (size_t)128 * WP + (size_t)(taps == 9 ? 180 : 128) * WP;
+  static bool attr_set[64] = {};
+  int dev = 0;
+  UNET_HIP_TRY(hipGetDevice(&dev));
+  if (!attr_set[dev & 63]) {
+    UNET_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&wgrad_mfma_kernel<9>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)((128 + 180) * WP)));
+    UNET_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&wgrad_mfma_kernel<1>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)((128 + 128) * WP)));
+    attr_set[dev & 63] = true;
+  }
+  dim3 grid((unsigned)splits, (unsigned)(a.CoP / 64), (unsigned)(a.CiP / 64));
+  const double partial_bytes = 4.0 * splits * taps * a.CoP * a.CiP;
+  {
+    ProfScope prof(taps == 9 ? PROF_CONV_WGRAD_BF16 : PROF_TCONV_WGRAD_BF16, flops,
+                   2.0 * a.N * a.H * a.W * ((double)a.x_c + a.z_c) + partial_bytes, s);
+    if (taps == 9)
+      hipLaunchKernelGGL(wgrad_mfma_kernel<9>, grid, dim3(256), lds, s, a);
+    else
+      hipLaunchKernelGGL(wgrad_mfma_kernel<1>, grid, dim3(256), lds, s, a);
+  }
+  UNET_LAUNCH_CHECK("wgrad_mfma_kernel");
+  ProfScope prof(PROF_WGRAD_REDUCE, 0, partial_bytes + 4.0 * taps * Co * Ci, s);
+  const i64 boxes = (i64)((Ci + 31) / 32) * ((Co + 7) / 8);
+  if (boxes >= 512 && splits <= 16) {
+    hipLaunchKernelGGL(wgrad_reduce_tile_kernel, dim3((unsigned)((Ci + 31) / 32), (unsigned)((Co + 7) / 8)), dim3(256), 0,
+                       s, (const float *)ws, grad, splits, taps, a.CoP, a.CiP, Co, Ci, taps_total, tap_base);
+  } else {
+    const i64 reduce_rows = (i64)taps * Co * ((Ci + 31) / 32);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(reduce_rows < 65536 ? reduce_rows : 65536)), dim3(256), 0,
+                       s, (const float *)ws, grad, splits, taps, a.CoP, a.CiP, Co, Ci, taps_total, tap_base);
+  }
+  UNET_LAUNCH_CHECK("wgrad_reduce_kernel");
+  return UNET_OK;
+}
+
+// grad_w [Ci][Co][3][3] fp32 (reference layout, overwritten)
+int unet_conv3x3_wgrad_bf16(const uint16_t *dz, int dz_ld, const uint16_t *x, int x_ld, float *grad_w, int N, int H,
+                            int W, int CiP, int CoP, int Ci, int Co, unet_stream_t s) {
+  UNET_REQUIRE(dz && x && grad_w, "unet_conv3x3_wgrad_bf16: NULL pointer");
+  UNET_REQUIRE(N > 0 && H > 0 && W > 0 && Ci > 0 && Co > 0 && Ci <= CiP && Co <= CoP,
+               "unet_conv3x3_wgrad_bf16: bad sizes");
+  UNET_REQUIRE(CiP % 8 == 0 && CoP % 8 == 0 && dz_ld >= CoP && x_ld >= CiP && dz_ld % 8 == 0 && x_ld % 8 == 0,
+               "unet_conv3x3_wgrad_bf16: padded channel counts and pixel strides must be multiples of 8");
+  UNET_REQUIRE((i64)H * W * x_ld < (1ll << 31) && (i64)H * W * dz_ld < (1ll << 31),
+               "unet_conv3x3_wgrad_bf16: one image must stay below 2^31 elements");
+  WgradArgs a{};
+  a.dz = dz; a.x = x; a.N = N; a.H = H; a.W = W; a.Hz = H; a.Wz = W; a.dz_ld = dz_ld; a.x_ld = x_ld;
+  a.CoP = (CoP + 63) / 64 * 64; a.CiP = (CiP + 63) / 64 * 64; a.z_c = CoP; a.x_c = CiP;
+  a.dz_s = 1; a.dz_oy = a.dz_ox = 0;
+  return run_wgrad(9, a, grad_w, Ci, Co, 9, 0, 2.0 * N * H * W * (double)CiP * CoP * 9, as_stream(s));
+}
+
+// grad_w [Ci][Co][2][2] fp32 (overwritten); x = the transposed conv's input, dy its output gradient
+int unet_tconv2x2_wgrad_bf16(const uint16_t *dy, int dy_ld, const uint16_t *x, int x_ld, float *grad_w, int N,
+                             int H_in, int W_in, int CiP, int CoP, int Ci, int Co, unet_stream_t s) {
+  UNET_REQUIRE(dy && x && grad_w, "unet_tconv2x2_wgrad_bf16: NULL pointer");
+  UNET_REQUIRE(N > 0 && H_in > 0 && W_in > 0 && Ci > 0 && Co > 0 && Ci <= CiP && Co <= CoP,
+               "unet_tconv2x2_wgrad_bf16: bad sizes");
+  UNET_REQUIRE(CiP % 8 == 0 && CoP % 8 == 0 && dy_ld >= CoP && x_ld >= CiP && dy_ld % 8 == 0 && x_ld % 8 == 0,
+               "unet_tconv2x2_wgrad_bf16: padded channel counts and pixel strides must be multiples of 8");
+  UNET_REQUIRE((i64)H_in * W_in * x_ld < (1ll << 31) && (i64)4 * H_in * W_in * dy_ld < (1ll << 31),
+               "unet_tconv2x2_wgrad_bf16: one image must stay below 2^31 elements");
+  for (int ph = 0; ph < 4; ++ph) {
+    WgradArgs a{};
+    a.dz = dy; a.x = x; a.N = N; a.H = H_in; a.W = W_in; a.Hz = 2 * H_in; a.Wz = 2 * W_in;
+    a.dz_ld = dy_ld; a.x_ld = x_ld; a.CoP = (CoP + 63) / 64 * 64; a.CiP = (CiP + 63) / 64 * 64;
+    a.z_c = CoP; a.x_c = CiP; a.dz_s = 2; a.dz_oy = ph >> 1; a.dz_ox = ph & 1;
+    int rc = run_wgrad(1, a, grad_w, Ci, Co, 4, ph, 2.0 * N * H_in * W_in * (double)CiP * CoP, as_stream(s));
+    if (rc) return rc;
+  }
+  return UNET_OK;
+}
+
+}  // extern "C"
