@@ -55,20 +55,20 @@ def conv_flops(graph, batch):
 
 def cpu_baseline_port(seconds_budget=30.0):
     """Times the CPU oracle (single thread, plain C) on a bounded sample of the
-    workload: one image through the 64->64 3x3 convolution at 256x256 (forward +
+    workload: three images through the 64->64 3x3 convolution at 256x256 (forward +
     backward), i.e. one of the two stage-1 convolutions; scales by FLOPs to an
     images/s figure for the whole step."""
     import oracle
     rng = np.random.default_rng(0)
     hw = 256
-    x = rng.standard_normal((1, 64, hw, hw)).astype(np.float32)
+    x = rng.standard_normal((3, 64, hw, hw)).astype(np.float32)
     w = (rng.standard_normal(64 * 64 * 9 + 64) * 0.05).astype(np.float32)
     t0 = time.perf_counter()
     y = oracle.convolve(x, w, 64, 3, 1, 1)
     dy = rng.standard_normal(y.shape).astype(np.float32)
     oracle.convolve_backward(x, dy, w, 3, 1, 1)
     dt = time.perf_counter() - t0
-    return dt, 3 * 2.0 * hw * hw * 64 * 64 * 9
+    return dt, 3 * 3 * 2.0 * hw * hw * 64 * 64 * 9
 
 
 def cpu_baseline_torch(graph, batch=1, steps=1):
@@ -234,6 +234,18 @@ def main():
             out["roofline"] = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 1), "peak": PEAK_HBM_GBS,
                                "unit": "GB/s", "frac": round(achieved / PEAK_HBM_GBS, 4), "traffic": None,
                                "avg_launch_us": round(f["ms"] * 1e3 / f["launches"], 2), "launches": f["launches"]}
+        # HBM-side bytes per launch of that kernel, measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
+        # (two passes of this same command, summarised by tools/summarize_pmc.py) -- only valid for
+        # the default workload the counters were collected on.
+        tpath = os.path.join(ROOT, "profiles", "hbm_traffic_per_kernel.json")
+        default_workload = args.graph == "unet4_base64" and args.batch == 16 and args.size == 256 and dtype == "bf16"
+        if default_workload and os.path.exists(tpath):
+            want = name.replace(",", ", ")
+            for kname, rec in json.load(open(tpath)).items():
+                if want in kname:
+                    out["roofline"]["traffic"] = rec["traffic_bytes_per_launch"]
+                    out["roofline"]["algorithmic_bytes_per_launch"] = round(f["bytes"] / f["launches"])
+                    break
         out["kernel_families"] = {
             k: {"launches": v["launches"], "ms_per_step": round(v["ms"] / args.steps, 3),
                 "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["flops"] else None,
@@ -245,7 +257,7 @@ def main():
         out["cpu_baseline"] = {
             "value": round(1.0 / (dt * img_flops / sample_flops), 5), "unit": "images/s", "cores": 1,
             "kind": "port",
-            "sample": f"C oracle, 1 image through one 64->64 3x3 conv at 256x256 fwd+bwd ({dt:.1f} s, "
+            "sample": f"C oracle, 3 images through one 64->64 3x3 conv at 256x256 fwd+bwd ({dt:.1f} s, "
                       f"{sample_flops / 1e9:.1f} GFLOP of {img_flops / 1e9:.0f} GFLOP/image), scaled by FLOPs"}
         try:
             tdt, cores = cpu_baseline_torch(graph, 1, 1)

@@ -316,27 +316,50 @@ int launch_conv_any(int taps, const ConvArgs &a, hipStream_t s) {
 //   fwd [tap][CoP][CiP] bf16 (tap = kh*K+kw), zero padded
 //   bwd [tap][CiP][CoP] bf16 with flipped taps for K=3 (data gradient as a forward conv over dZ);
 //       unflipped for the transposed-conv phases (K=2, taps are the (i,j) phases)
-// A workgroup moves a 32(ci) x 32(co) x taps box: contiguous reads of the reference layout into
-// LDS, then 64-byte runs along ci (fwd) and along co (bwd).
+// A workgroup moves a 32(ci) x 32(co) x taps box: contiguous 16-byte reads of the reference layout
+// into LDS, then each lane packs 8 consecutive bf16 and stores 16 bytes: 64-byte runs along ci (fwd)
+// and along co (bwd).
+template <int K>
 __global__ __launch_bounds__(256) void pack_weights_kernel(const float *__restrict__ w, bf16_t *__restrict__ fwd,
                                                            bf16_t *__restrict__ bwd, int Ci, int Co, int CiP,
-                                                           int CoP, int K) {
-  __shared__ float tile[32 * (32 * 9 + 1)];
-  const int taps = K * K, run = 32 * taps, pitch = run + 1;
+                                                           int CoP) {
+  constexpr int taps = K * K, run = 32 * taps, pitch = run + 1;
+  __shared__ float tile[32 * pitch];
   const int ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32;
-  for (int idx = threadIdx.x; idx < 32 * run; idx += 256) {
-    const int cl = idx / run, rem = idx - cl * run;
-    const int ci = ci0 + cl, co = co0 + rem / taps;
-    tile[cl * pitch + rem] = (ci < Ci && co < Co) ? w[((i64)ci * Co + co0) * taps + rem] : 0.f;
+  const bool full = ci0 + 32 <= Ci && co0 + 32 <= Co && (Co * taps) % 4 == 0 && (reinterpret_cast<uintptr_t>(w) & 15) == 0;
+  if (full) {
+    for (int idx = threadIdx.x; idx < 32 * (run / 4); idx += 256) {
+      const int cl = idx / (run / 4), r4 = idx - cl * (run / 4);
+      const float4 v = *reinterpret_cast<const float4 *>(w + ((i64)(ci0 + cl) * Co + co0) * taps + 4 * r4);
+      float *d = tile + cl * pitch + 4 * r4;
+      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+  } else {
+    for (int idx = threadIdx.x; idx < 32 * run; idx += 256) {
+      const int cl = idx / run, rem = idx - cl * run;
+      const int ci = ci0 + cl, co = co0 + rem / taps;
+      tile[cl * pitch + rem] = (ci < Ci && co < Co) ? w[((i64)ci * Co + co0) * taps + rem] : 0.f;
+    }
   }
   __syncthreads();
-  for (int idx = threadIdx.x; idx < taps * 1024; idx += 256) {
-    const int a = idx & 31, b = (idx >> 5) & 31, t = idx >> 10;
-    if (fwd)  // a = ci (fastest), b = co
-      fwd[((i64)t * CoP + co0 + b) * CiP + ci0 + a] = (bf16_t)f32_to_bf16(tile[a * pitch + b * taps + t]);
-    if (bwd) {  // a = co (fastest), b = ci
+  for (int idx = threadIdx.x; idx < taps * 128; idx += 256) {
+    const int a = (idx & 3) * 8, b = (idx >> 2) & 31, t = idx >> 7;
+    if (fwd) {  // a = first of 8 consecutive ci, b = co
+      uint32_t v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        v[j] = f32_to_bf16(tile[(a + 2 * j) * pitch + b * taps + t]) |
+               (f32_to_bf16(tile[(a + 2 * j + 1) * pitch + b * taps + t]) << 16);
+      *reinterpret_cast<uint4 *>(fwd + ((i64)t * CoP + co0 + b) * CiP + ci0 + a) = make_uint4(v[0], v[1], v[2], v[3]);
+    }
+    if (bwd) {  // a = first of 8 consecutive co, b = ci
       const int tb = (K == 3) ? (taps - 1 - t) : t;
-      bwd[((i64)tb * CiP + ci0 + b) * CoP + co0 + a] = (bf16_t)f32_to_bf16(tile[b * pitch + a * taps + t]);
+      uint32_t v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        v[j] = f32_to_bf16(tile[b * pitch + (a + 2 * j) * taps + t]) |
+               (f32_to_bf16(tile[b * pitch + (a + 2 * j + 1) * taps + t]) << 16);
+      *reinterpret_cast<uint4 *>(bwd + ((i64)tb * CiP + ci0 + b) * CoP + co0 + a) = make_uint4(v[0], v[1], v[2], v[3]);
     }
   }
 }
@@ -393,8 +416,11 @@ int unet_pack_weights_bf16(const float *w_ref, uint16_t *w_fwd, uint16_t *w_bwd,
   UNET_REQUIRE(w_ref && (w_fwd || w_bwd), "unet_pack_weights_bf16: NULL pointer");
   UNET_REQUIRE(Ci > 0 && Co > 0 && CiP >= Ci && CoP >= Co && (K == 3 || K == 2) && CiP % 32 == 0 && CoP % 32 == 0,
                "unet_pack_weights_bf16: need K in {2,3} and padded channel counts that are multiples of 32");
-  hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)(CiP / 32), (unsigned)(CoP / 32)), dim3(256), 0, as_stream(s),
-                     w_ref, w_fwd, w_bwd, Ci, Co, CiP, CoP, K);
+  const dim3 grid((unsigned)(CiP / 32), (unsigned)(CoP / 32));
+  if (K == 3)
+    hipLaunchKernelGGL(pack_weights_kernel<3>, grid, dim3(256), 0, as_stream(s), w_ref, w_fwd, w_bwd, Ci, Co, CiP, CoP);
+  else
+    hipLaunchKernelGGL(pack_weights_kernel<2>, grid, dim3(256), 0, as_stream(s), w_ref, w_fwd, w_bwd, Ci, Co, CiP, CoP);
   UNET_LAUNCH_CHECK("pack_weights_kernel");
   return UNET_OK;
 }

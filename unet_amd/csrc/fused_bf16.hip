@@ -51,7 +51,19 @@ __device__ __forceinline__ void wave_sum_partials(const float *__restrict__ part
                                                    double &s, double &q) {
   const int lane = threadIdx.x & 63;
   double a = 0, b = 0;
-  for (int p = lane; p < P; p += 64) {
+  int p = lane;
+  // eight independent strided loads in flight per lane
+  for (; p + 7 * 64 < P; p += 8 * 64) {
+    float2 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float2 *>(partials + ((i64)(p + u * 64) * CoP + c) * 2);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      a += v[u].x;
+      b += v[u].y;
+    }
+  }
+  for (; p < P; p += 64) {
     const float2 v = *reinterpret_cast<const float2 *>(partials + ((i64)p * CoP + c) * 2);
     a += v.x;
     b += v.y;
@@ -344,7 +356,15 @@ __global__ __launch_bounds__(256) void column_sum_kernel(const float *__restrict
   if (c >= C) return;
   const int lane = threadIdx.x & 63;
   double s = 0;
-  for (int p = lane; p < P; p += 64) s += partial[(i64)p * stride + c];
+  int p = lane;
+  for (; p + 7 * 64 < P; p += 8 * 64) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = partial[(i64)(p + u * 64) * stride + c];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];
+  }
+  for (; p < P; p += 64) s += partial[(i64)p * stride + c];
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
   if (lane == 0) out[c] = (float)s;
