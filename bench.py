@@ -151,11 +151,51 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(device)
 
+    # Timer families -> kernels.  The forward and data-gradient 3x3 convolutions are the same
+    # kernel (conv_mfma_kernel<9,64>; the data gradient runs it on flipped weights).
+    kernel_of = {"conv3x3_fwd_bf16": "conv_mfma_kernel<9,64>", "conv3x3_dgrad_bf16": "conv_mfma_kernel<9,64>",
+                 "conv3x3_wgrad_bf16": "wgrad_mfma_kernel<9>", "tconv2x2_bf16": "conv_mfma_kernel<1,64>",
+                 "tconv2x2_wgrad_bf16": "wgrad_mfma_kernel<1>"}
+
+    def read_families():
+        fams = {}
+        kinds = ctypes.c_int()
+        capi.unet_prof_kinds(ctypes.byref(kinds))
+        for k in range(kinds.value):
+            n, ms, fl, by = ctypes.c_int64(), ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+            capi.unet_prof_get(k, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(by))
+            if n.value:
+                fams[capi.lib().unet_prof_name(k).decode()] = dict(
+                    kind=k, launches=n.value, ms=ms.value, flops=fl.value, bytes=by.value)
+        return fams
+
+    def group_kernels(fams):
+        kernels = {}
+        for fam, f in fams.items():
+            k = kernels.setdefault(kernel_of.get(fam, fam), dict(launches=0, ms=0.0, flops=0.0, bytes=0.0, mask=0))
+            for key in ("launches", "ms", "flops", "bytes"):
+                k[key] += f[key]
+            k["mask"] |= 1 << f["kind"]
+        return kernels
+
     for _ in range(args.warmup):
         trainer.train_step(images.data_ptr(), masks.data_ptr(), args.batch, lr)
     sync()
-    if not args.no_prof:
+
+    # Untimed probe: every kernel family timed with HIP events (two event records per launch cost
+    # about 1 ms per step, so this pass is kept out of the timed region).  It yields the per-family
+    # table and names the dominant kernel.
+    probe_steps = 0 if args.no_prof else 3
+    probe, dominant_mask = {}, 0
+    if probe_steps:
         capi.unet_prof_enable(1)
+        for _ in range(probe_steps):
+            trainer.train_step(images.data_ptr(), masks.data_ptr(), args.batch, lr)
+        sync()
+        probe = read_families()
+        dominant_mask = max(group_kernels(probe).values(), key=lambda k: k["ms"])["mask"]
+        # Timed region: events only around the launches of the dominant kernel.
+        capi.unet_prof_enable_kinds(dominant_mask)
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -167,17 +207,9 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # per-kernel-family timing from the HIP events recorded in the timed region
     families = {}
-    if not args.no_prof:
-        kinds = ctypes.c_int()
-        capi.unet_prof_kinds(ctypes.byref(kinds))
-        for k in range(kinds.value):
-            n, ms, fl, by = ctypes.c_int64(), ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
-            capi.unet_prof_get(k, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(by))
-            if n.value:
-                families[capi.lib().unet_prof_name(k).decode()] = dict(
-                    launches=n.value, ms=ms.value, flops=fl.value, bytes=by.value)
+    if probe_steps:
+        families = read_families()   # the dominant kernel's families, timed inside the timed region
         capi.unet_prof_enable(0)
 
     loss = None
@@ -209,20 +241,11 @@ def main():
         "final_loss": loss,
     }
     if families:
-        # Timer families -> kernels.  The forward and data-gradient 3x3 convolutions are the same
-        # kernel (conv_mfma_kernel<9,64>, the data gradient runs it on flipped weights).
-        kernel_of = {"conv3x3_fwd_bf16": "conv_mfma_kernel<9,64>", "conv3x3_dgrad_bf16": "conv_mfma_kernel<9,64>",
-                     "conv3x3_wgrad_bf16": "wgrad_mfma_kernel<9>", "tconv2x2_bf16": "conv_mfma_kernel<1,64>",
-                     "tconv2x2_wgrad_bf16": "wgrad_mfma_kernel<1>"}
         mfma_bound = {"conv_mfma_kernel<9,64>", "wgrad_mfma_kernel<9>", "conv_mfma_kernel<1,64>",
                       "wgrad_mfma_kernel<1>", "conv_fwd_f32", "conv_dgrad_f32", "conv_wgrad_f32", "tconv_f32"}
-        kernels = {}
-        for fam, f in families.items():
-            k = kernels.setdefault(kernel_of.get(fam, fam), dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
-            for key in k:
-                k[key] += f[key]
-        # dominant kernel = the one with the largest share of device time
-        name, f = max(kernels.items(), key=lambda kv: kv[1]["ms"])
+        # dominant kernel = the one with the largest share of device time in the probe pass; its
+        # launches were timed live in the timed region
+        (name, f), = group_kernels(families).items()
         if name in mfma_bound:
             achieved = f["flops"] / (f["ms"] * 1e-3) / 1e12
             peak = PEAK_TFLOPS["f32" if name.endswith("f32") else "bf16"]
@@ -246,11 +269,12 @@ def main():
                     out["roofline"]["traffic"] = rec["traffic_bytes_per_launch"]
                     out["roofline"]["algorithmic_bytes_per_launch"] = round(f["bytes"] / f["launches"])
                     break
+        # per-family table from the untimed probe pass (all families timed)
         out["kernel_families"] = {
-            k: {"launches": v["launches"], "ms_per_step": round(v["ms"] / args.steps, 3),
+            k: {"launches_per_step": v["launches"] // probe_steps, "ms_per_step": round(v["ms"] / probe_steps, 3),
                 "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["flops"] else None,
                 "gbs": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["bytes"] else None}
-            for k, v in sorted(families.items(), key=lambda kv: -kv[1]["ms"])}
+            for k, v in sorted(probe.items(), key=lambda kv: -kv[1]["ms"])}
     if world == 1 and not args.no_cpu_baseline:
         dt, sample_flops = cpu_baseline_port()
         img_flops = step_flops / args.batch

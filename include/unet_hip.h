@@ -75,6 +75,10 @@ int unet_event_elapsed_ms(float *ms, unet_event_t start, unet_event_t stop);
  * launches, their summed duration, and the algorithmic FLOPs and bytes the
  * launchers attributed to them. */
 int unet_prof_enable(int on);
+/* Same, but records only the families whose bit (1 << kind) is set in
+ * kind_mask: timing one kernel family costs two event records per launch of
+ * that family and nothing for the others. */
+int unet_prof_enable_kinds(uint64_t kind_mask);
 int unet_prof_kinds(int *count);
 const char *unet_prof_name(int kind);
 int unet_prof_get(int kind, int64_t *launches, double *total_ms, double *total_flops, double *total_bytes);

@@ -72,6 +72,7 @@ struct ProfRec {
 };
 std::mutex g_prof_mu;
 bool g_prof_enabled = false;
+uint64_t g_prof_mask = ~0ull;
 std::vector<ProfRec> g_prof_recs;
 std::vector<hipEvent_t> g_prof_pool;
 const char *kProfNames[PROF_KINDS] = {
@@ -93,6 +94,7 @@ hipEvent_t prof_event() {
 
 bool unet_prof_on() { return g_prof_enabled; }
 void unet_prof_mark(int kind, double flops, double bytes, hipStream_t s, bool begin) {
+  if (!((g_prof_mask >> kind) & 1ull)) return;
   std::lock_guard<std::mutex> lk(g_prof_mu);
   if (begin) {
     ProfRec r{kind, flops, bytes, prof_event(), prof_event()};
@@ -117,7 +119,13 @@ int unet_prof_enable(int on) {
   }
   g_prof_recs.clear();
   g_prof_enabled = on != 0;
+  g_prof_mask = ~0ull;
   return UNET_OK;
+}
+int unet_prof_enable_kinds(uint64_t kind_mask) {
+  int rc = unet_prof_enable(kind_mask != 0);
+  g_prof_mask = kind_mask;
+  return rc;
 }
 int unet_prof_kinds(int *count) {
   UNET_REQUIRE(count, "count is NULL");
