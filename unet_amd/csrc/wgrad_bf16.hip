@@ -29,6 +29,7 @@ struct WgradArgs {
   int dz_s, dz_oy, dz_ox;  // dz pixel of logical (y,x): (y*dz_s+dz_oy, x*dz_s+dz_ox)
   int chunksX, chunksY;    // 8x16 pixel chunks per image
   int chunks_per_split, total_chunks;
+  int phases;  // TAPS == 1 only: 4 = blockIdx.x also selects the (i,j) phase of a 2x2 transposed conv
 };
 
 constexpr int WP = 192;  // LDS row pitch (bytes) of a 64-channel pixel row: 4 rows x 64 B fall in 4 distinct bank quarters
@@ -50,7 +51,14 @@ __global__ __launch_bounds__(256, 1) void wgrad_mfma_kernel(const WgradArgs a) {
   unsigned char *ldsZ = lds, *ldsX = lds + ZPIX * WP;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int co0 = blockIdx.y * 64, ci0 = blockIdx.z * 64, split = blockIdx.x;
+  const int co0 = blockIdx.y * 64, ci0 = blockIdx.z * 64;
+  int split = blockIdx.x, phase = 0, dz_oy = a.dz_oy, dz_ox = a.dz_ox;
+  if (TAPS == 1 && a.phases > 1) {
+    phase = split & 3;
+    split >>= 2;
+    dz_oy = phase >> 1;
+    dz_ox = phase & 1;
+  }
   const int wm = wave >> 1, wn = wave & 1;
 
   f32x16 acc[TAPS];
@@ -86,7 +94,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_mfma_kernel(const WgradArgs a) {
     const int pix = (tid + 256 * i) >> 3;
     z_py[i] = z_ch_ok ? (pix >> 4) : -100000;
     z_px[i] = pix & 15;
-    z_rel[i] = (unsigned)((((z_py[i] * a.dz_s + a.dz_oy) * a.Wz + z_px[i] * a.dz_s + a.dz_ox) * a.dz_ld + co0 + part * 8) * 2);
+    z_rel[i] = (unsigned)((((z_py[i] * a.dz_s + dz_oy) * a.Wz + z_px[i] * a.dz_s + dz_ox) * a.dz_ld + co0 + part * 8) * 2);
   }
   const unsigned x_img_bytes = (unsigned)a.H * a.W * a.x_ld * 2u, z_img_bytes = (unsigned)a.Hz * a.Wz * a.dz_ld * 2u;
   const int st_off = (tid >> 3) * WP + (tid & 7) * 16;  // piece i sits 32 pixel rows further
@@ -145,7 +153,8 @@ __global__ __launch_bounds__(256, 1) void wgrad_mfma_kernel(const WgradArgs a) {
     }
   }
   // partial[split][tap][co][ci] through one descriptor per split slice and 32-bit offsets
-  const auto prs = __builtin_amdgcn_make_buffer_rsrc(a.partial + (i64)split * TAPS * a.CoP * a.CiP, 0,
+  const int slices = (TAPS == 1 && a.phases > 1) ? a.phases : TAPS;  // tap slices per split in the partial buffer
+  const auto prs = __builtin_amdgcn_make_buffer_rsrc(a.partial + ((i64)split * slices + phase) * a.CoP * a.CiP, 0,
                                                      (unsigned)TAPS * a.CoP * a.CiP * 4u, 0x00020000);
   const unsigned row_bytes = (unsigned)a.CiP * 4u;
   unsigned off = ((unsigned)(co0 + wm * 32 + 4 * (lane >> 5)) * a.CiP + ci0 + wn * 32 + (lane & 31)) * 4u;
@@ -230,22 +239,26 @@ __global__ __launch_bounds__(256) void wgrad_reduce_tile_kernel(const float *__r
 
 extern "C" {
 
-static int run_wgrad(int taps, const WgradArgs &base, float *grad, int Ci, int Co, int taps_total, int tap_base,
-                     double flops, hipStream_t s) {
+// taps = 9: 3x3 convolution.  taps = 1 with phases = 4: the four (i,j) phases of the 2x2 transposed
+// convolution, one phase per workgroup, reduced together as a 4-tap filter.
+static int run_wgrad(int taps, int phases, const WgradArgs &base, float *grad, int Ci, int Co, double flops,
+                     hipStream_t s) {
   WgradArgs a = base;
+  a.phases = phases;
+  const int slices = taps * phases;  // tap slices per split in the partial buffer
   a.chunksX = (a.W + 15) / 16;
   a.chunksY = (a.H + 7) / 8;
   a.total_chunks = a.N * a.chunksX * a.chunksY;
   const int tiles = (a.CoP / 64) * (a.CiP / 64);
   // two workgroups per CU's worth of blocks: small enough slices that a CU lent to a concurrent
   // collective costs little, large enough that the partial sums stay a minor part of the traffic
-  int splits = (512 + tiles - 1) / tiles;
+  int splits = (512 / phases + tiles - 1) / tiles;
   if (splits > a.total_chunks) splits = a.total_chunks;
   if (splits < 1) splits = 1;
   a.chunks_per_split = (a.total_chunks + splits - 1) / splits;
   splits = (a.total_chunks + a.chunks_per_split - 1) / a.chunks_per_split;
   void *ws;
-  int rc = unet_workspace(&ws, sizeof(float) * (size_t)splits * taps * a.CoP * a.CiP);
+  int rc = unet_workspace(&ws, sizeof(float) * (size_t)splits * slices * a.CoP * a.CiP);
   if (rc) return rc;
   a.partial = (float *)ws;
   const size_t lds = (size_t)128 * WP + (size_t)(taps == 9 ? 180 : 128) * WP;
@@ -259,26 +272,26 @@ static int run_wgrad(int taps, const WgradArgs &base, float *grad, int Ci, int C
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)((128 + 128) * WP)));
     attr_set[dev & 63] = true;
   }
-  dim3 grid((unsigned)splits, (unsigned)(a.CoP / 64), (unsigned)(a.CiP / 64));
-  const double partial_bytes = 4.0 * splits * taps * a.CoP * a.CiP;
+  dim3 grid((unsigned)(splits * phases), (unsigned)(a.CoP / 64), (unsigned)(a.CiP / 64));
+  const double partial_bytes = 4.0 * splits * slices * a.CoP * a.CiP;
   {
     ProfScope prof(taps == 9 ? PROF_CONV_WGRAD_BF16 : PROF_TCONV_WGRAD_BF16, flops,
-                   2.0 * a.N * a.H * a.W * ((double)a.x_c + a.z_c) + partial_bytes, s);
+                   2.0 * a.N * a.H * a.W * ((double)a.x_c * phases + (double)a.z_c * phases) + partial_bytes, s);
     if (taps == 9)
       hipLaunchKernelGGL(wgrad_mfma_kernel<9>, grid, dim3(256), lds, s, a);
     else
       hipLaunchKernelGGL(wgrad_mfma_kernel<1>, grid, dim3(256), lds, s, a);
   }
   UNET_LAUNCH_CHECK("wgrad_mfma_kernel");
-  ProfScope prof(PROF_WGRAD_REDUCE, 0, partial_bytes + 4.0 * taps * Co * Ci, s);
+  ProfScope prof(PROF_WGRAD_REDUCE, 0, partial_bytes + 4.0 * slices * Co * Ci, s);
   const i64 boxes = (i64)((Ci + 31) / 32) * ((Co + 7) / 8);
   if (boxes >= 512 && splits <= 16) {
     hipLaunchKernelGGL(wgrad_reduce_tile_kernel, dim3((unsigned)((Ci + 31) / 32), (unsigned)((Co + 7) / 8)), dim3(256), 0,
-                       s, (const float *)ws, grad, splits, taps, a.CoP, a.CiP, Co, Ci, taps_total, tap_base);
+                       s, (const float *)ws, grad, splits, slices, a.CoP, a.CiP, Co, Ci, slices, 0);
   } else {
-    const i64 reduce_rows = (i64)taps * Co * ((Ci + 31) / 32);
+    const i64 reduce_rows = (i64)slices * Co * ((Ci + 31) / 32);
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(reduce_rows < 65536 ? reduce_rows : 65536)), dim3(256), 0,
-                       s, (const float *)ws, grad, splits, taps, a.CoP, a.CiP, Co, Ci, taps_total, tap_base);
+                       s, (const float *)ws, grad, splits, slices, a.CoP, a.CiP, Co, Ci, slices, 0);
   }
   UNET_LAUNCH_CHECK("wgrad_reduce_kernel");
   return UNET_OK;
@@ -298,7 +311,7 @@ int unet_conv3x3_wgrad_bf16(const uint16_t *dz, int dz_ld, const uint16_t *x, in
   a.dz = dz; a.x = x; a.N = N; a.H = H; a.W = W; a.Hz = H; a.Wz = W; a.dz_ld = dz_ld; a.x_ld = x_ld;
   a.CoP = (CoP + 63) / 64 * 64; a.CiP = (CiP + 63) / 64 * 64; a.z_c = CoP; a.x_c = CiP;
   a.dz_s = 1; a.dz_oy = a.dz_ox = 0;
-  return run_wgrad(9, a, grad_w, Ci, Co, 9, 0, 2.0 * N * H * W * (double)CiP * CoP * 9, as_stream(s));
+  return run_wgrad(9, 1, a, grad_w, Ci, Co, 2.0 * N * H * W * (double)CiP * CoP * 9, as_stream(s));
 }
 
 // grad_w [Ci][Co][2][2] fp32 (overwritten); x = the transposed conv's input, dy its output gradient
@@ -311,15 +324,11 @@ int unet_tconv2x2_wgrad_bf16(const uint16_t *dy, int dy_ld, const uint16_t *x, i
                "unet_tconv2x2_wgrad_bf16: padded channel counts and pixel strides must be multiples of 8");
   UNET_REQUIRE((i64)H_in * W_in * x_ld < (1ll << 31) && (i64)4 * H_in * W_in * dy_ld < (1ll << 31),
                "unet_tconv2x2_wgrad_bf16: one image must stay below 2^31 elements");
-  for (int ph = 0; ph < 4; ++ph) {
-    WgradArgs a{};
-    a.dz = dy; a.x = x; a.N = N; a.H = H_in; a.W = W_in; a.Hz = 2 * H_in; a.Wz = 2 * W_in;
-    a.dz_ld = dy_ld; a.x_ld = x_ld; a.CoP = (CoP + 63) / 64 * 64; a.CiP = (CiP + 63) / 64 * 64;
-    a.z_c = CoP; a.x_c = CiP; a.dz_s = 2; a.dz_oy = ph >> 1; a.dz_ox = ph & 1;
-    int rc = run_wgrad(1, a, grad_w, Ci, Co, 4, ph, 2.0 * N * H_in * W_in * (double)CiP * CoP, as_stream(s));
-    if (rc) return rc;
-  }
-  return UNET_OK;
+  WgradArgs a{};
+  a.dz = dy; a.x = x; a.N = N; a.H = H_in; a.W = W_in; a.Hz = 2 * H_in; a.Wz = 2 * W_in;
+  a.dz_ld = dy_ld; a.x_ld = x_ld; a.CoP = (CoP + 63) / 64 * 64; a.CiP = (CiP + 63) / 64 * 64;
+  a.z_c = CoP; a.x_c = CiP; a.dz_s = 2; a.dz_oy = a.dz_ox = 0;
+  return run_wgrad(1, 4, a, grad_w, Ci, Co, 2.0 * N * H_in * W_in * 4.0 * CiP * CoP, as_stream(s));
 }
 
 }  // extern "C"
