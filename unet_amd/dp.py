@@ -90,12 +90,31 @@ class DataParallel:
     def _wait_event(self, stream, event):
         self._capi.unet_stream_wait_event(stream.cuda_stream, event)
 
+    def reduce_gradients(self):
+        """Averages the gradient buffer over the ranks, bucket by bucket, each
+        bucket as soon as backward has finished it."""
+        if self.world == 1:
+            return
+        if dist.get_backend(self.group) == "nccl":
+            works = allreduce_mean_(self.grads, self.buckets, self.group, (self.comm, self._wait_event))
+            for w in works:
+                w.wait()      # the compute stream waits for the reduced bucket
+            return
+        # Transports without device collectives (gloo, used by the single-GPU rehearsal of the
+        # multi-rank path): stage each finished bucket through host memory.
+        for off, cnt, ev in self.buckets:
+            if ev:
+                self._capi.unet_event_synchronize(ev)
+            else:
+                self.net.synchronize()
+            host = self.grads[off:off + cnt].cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+            self.grads[off:off + cnt].copy_(host.div_(self.world))
+        torch.cuda.synchronize(self.device)
+
     def train_step(self, images_ptr, masks_ptr, batch, lr):
         """Enqueues forward, backward, the bucketed all-reduce and the Adam step
         for this rank's shard (device pointers); does not synchronise."""
         self.net.forward_backward_device(images_ptr, masks_ptr, batch)
-        if self.world > 1:
-            works = allreduce_mean_(self.grads, self.buckets, self.group, (self.comm, self._wait_event))
-            for w in works:
-                w.wait()      # the compute stream waits for the reduced bucket
+        self.reduce_gradients()
         self.net.step(lr)
