@@ -1,0 +1,183 @@
+"""The benchmark configurations at their full sizes.
+
+  config 1: full U-Net forward (4 down / 4 up, base 64), 1x3x256x256, fp32 inference
+            -> against the PyTorch-CPU float64 oracle (fp32 bar, and the bf16 path at its bar)
+  config 2: train step, batch 16x3x256x256, bf16
+            -> the float64 oracle needs minutes of CPU at this size, so the full-size checks are
+               size-independent properties: bit-identical repeat runs, per-sample independence of
+               the forward pass, and agreement with the engine's own fp32 path (which the small
+               tests pin to the oracle) on loss and gradient direction.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import torch_ref
+from util import assert_close_bf16_net
+
+pytestmark = pytest.mark.gpu
+os.environ.setdefault("UNET_QUIET", "1")
+
+H = 256
+
+
+@pytest.fixture(scope="module")
+def nn():
+    import neural_net
+    return neural_net
+
+
+def _make(nn, graph, dtype, seed=11):
+    old = os.environ.get("UNET_DTYPE")
+    os.environ["UNET_DTYPE"] = dtype
+    try:
+        net = nn.NeuralNet()
+        net.set_seed(seed)
+        net.create(torch_ref.to_layer_descs(nn, graph), nn.LossFunction.DICE_LOSS)
+    finally:
+        if old is None:
+            del os.environ["UNET_DTYPE"]
+        else:
+            os.environ["UNET_DTYPE"] = old
+    return net
+
+
+@pytest.fixture(scope="module")
+def graph():
+    return torch_ref.unet_graph(H, H, 3, 64, 4, True)
+
+
+@pytest.fixture(scope="module")
+def inference_case(nn, graph):
+    """Parameters and running statistics after one fp32 training step, the input image, and the
+    float64 oracle's inference output."""
+    rng = np.random.default_rng(21)
+    x = rng.standard_normal((2, 3, H, H)).astype(np.float32)
+    m = (rng.random((2, H, H)) < 0.03).astype(np.float32)
+    net = _make(nn, graph, "fp32")
+    net.train_step(x, m, 1e-3, True)          # moves the running statistics and the weights
+    params = net.get_parameters()
+    running = [net.running_stats(i) for i in range(len(graph))]
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    acts = torch_ref.forward(graph, torch_ref.split_params(graph, params), torch.from_numpy(x[:1]).double(),
+                             training=False, running=running)
+    return net, params, running, x, acts[-1].detach().numpy()
+
+
+def test_config1_unet_forward_fp32_inference(nn, graph, inference_case):
+    net, params, running, x, want = inference_case
+    assert net.compute_dtype() == "f32"
+    got = net.forward(x[:1], True)
+    assert got.shape == (1, 1, H, H)
+    rel = np.linalg.norm(got - want) / np.linalg.norm(want)
+    assert rel <= 1e-4, rel
+    assert np.abs(got - want).max() <= 1e-4, np.abs(got - want).max()      # sigmoid outputs in [0,1]
+    mask = net.infer(x[0])
+    flips = (mask[0] != (want[0, 0] >= 0.5)).mean()
+    assert flips <= 1e-4, flips                                           # only pixels within 1e-4 of 0.5 may differ
+
+
+def test_config1_unet_forward_bf16_inference(nn, graph, inference_case):
+    _, params, running, x, want = inference_case
+    net = _make(nn, graph, "bf16")
+    assert net.compute_dtype() == "bf16"
+    net.set_parameters(params)
+    # bring the bf16 net's running statistics to the same state: same data, same single step
+    rng = np.random.default_rng(21)
+    x2 = rng.standard_normal((2, 3, H, H)).astype(np.float32)
+    m2 = (rng.random((2, H, H)) < 0.03).astype(np.float32)
+    fresh = _make(nn, graph, "bf16")
+    fresh.train_step(x2, m2, 1e-3, True)
+    for i in range(len(graph)):
+        r = fresh.running_stats(i)
+        if len(r):
+            assert np.abs(np.asarray(r) - np.asarray(running[i])).max() <= 2e-2 * max(1.0, np.abs(running[i]).max())
+    fresh.set_parameters(params)
+    got = fresh.forward(x[:1], True)
+    # 23 bf16 layers deep: relative L2 bound grows with the square root of the depth
+    assert_close_bf16_net(got, want, "bf16 inference output", rel_bar=max(2e-2, 0.8e-2 * np.sqrt(23)), guard=False)
+
+
+def test_config2_train_step_full_size_properties(nn, graph):
+    rng = np.random.default_rng(22)
+    n = 16
+    x = rng.standard_normal((n, 3, H, H)).astype(np.float32)
+    m = (rng.random((n, H, H)) < 0.03).astype(np.float32)
+    a = _make(nn, graph, "bf16")
+    b = _make(nn, graph, "bf16")
+    p0 = a.get_parameters()
+    assert np.array_equal(p0, b.get_parameters())
+    la = a.train_step(x, m, 1e-3, True)
+    lb = b.train_step(x, m, 1e-3, True)
+    ga, gb = a.get_gradients(), b.get_gradients()
+    assert np.isfinite(la) and np.isfinite(ga).all()
+    assert la == lb and np.array_equal(ga, gb), "repeat runs must be bit-identical"
+    assert np.array_equal(a.get_parameters(), b.get_parameters())
+    # inference is per-sample independent: a batch gives the same rows as single images
+    yb = a.forward(x[:3], True)
+    for i in range(3):
+        assert np.array_equal(yb[i], a.forward(x[i:i + 1], True)[0])
+    # the fp32 path on the same step: same loss, same gradient magnitude per tensor; the direction
+    # agrees closely next to the loss and drifts smoothly with depth (every bf16 layer flips the
+    # ReLU mask of the few pre-activations that sit next to zero, which is noise, not bias)
+    f = _make(nn, graph, "fp32")
+    f.set_parameters(p0)
+    lf = f.train_step(x, m, 1e-3, False)
+    gf = f.get_gradients().astype(np.float64)
+    ga = ga.astype(np.float64)
+    assert abs(la - lf) <= 2e-2 * abs(lf), (la, lf)
+    cos = lambda u, v: float(np.dot(u, v) / (np.linalg.norm(u) * np.linalg.norm(v)))
+    assert cos(ga, gf) >= 0.6, cos(ga, gf)
+    off, per_layer = 0, []
+    for kind, sh, _, _ in graph:
+        if kind in ("conv", "up"):
+            nw = sh[2] * sh[3] * sh[4] * sh[4]
+            u, v = ga[off:off + nw], gf[off:off + nw]
+            per_layer.append(cos(u, v))
+            ratio = np.linalg.norm(u) / np.linalg.norm(v)
+            assert 0.9 <= ratio <= 1.1, (kind, sh, ratio)
+            off += nw + 3 * sh[3]
+    assert per_layer[-1] >= 0.98 and per_layer[-2] >= 0.93, per_layer[-3:]
+    assert min(per_layer) >= 0.5, per_layer
+
+
+def test_config2_shape_one_image_against_emulating_oracle(nn, graph):
+    """Full-size graph and image, batch 1 (the float64 oracle takes ~0.3 TFLOP per image): every
+    activation and the gradients against the oracle that stores what the engine stores in bf16."""
+    rng = np.random.default_rng(23)
+    x = rng.standard_normal((1, 3, H, H)).astype(np.float32)
+    m = (rng.random((1, H, H)) < 0.03).astype(np.float32)
+    net = _make(nn, graph, "bf16")
+    p0 = net.get_parameters()
+    loss = net.train_step(x, m, 1e-3, False)
+    g = net.get_gradients().astype(np.float64)
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    params = torch_ref.split_params(graph, p0)
+    acts = torch_ref.forward(graph, params, torch.from_numpy(x).double(), training=True, emulate_bf16=True)
+    ref_loss = torch_ref.dice_loss(acts[-1], torch.from_numpy(m).double())
+    ref_loss.backward()
+    ref_g = torch_ref.flat_grads(graph, params)
+    assert abs(loss - ref_loss.item()) <= 2e-3 * abs(ref_loss.item()), (loss, ref_loss.item())
+    assert_close_bf16_net(net.layer_output(len(graph) - 1, 1), acts[-1].detach().numpy(), "network output",
+                          rel_bar=2e-2, guard=False)
+    # Direction of the full gradient.  At this depth the Dice gradient reaches the early layers
+    # through 23 batch norms that cancel most of it, so the remainder is sensitive to which
+    # pre-activations round across zero; the small graphs of test_module_bf16_gpu.py hold the same
+    # comparison to 0.99.
+    c = float(np.dot(g, ref_g) / (np.linalg.norm(g) * np.linalg.norm(ref_g)))
+    assert c >= 0.8, c
+    # The engine's fp32 path on the same image against the plain float64 oracle: tight, which
+    # pins the large-shape code paths (many tiles, split-K, 1024 channels) independently of bf16.
+    f = _make(nn, graph, "fp32")
+    f.set_parameters(p0)
+    f.train_step(x, m, 1e-3, False)
+    gf = f.get_gradients().astype(np.float64)
+    params64 = torch_ref.split_params(graph, p0)
+    acts64 = torch_ref.forward(graph, params64, torch.from_numpy(x).double(), training=True)
+    torch_ref.dice_loss(acts64[-1], torch.from_numpy(m).double()).backward()
+    g64 = torch_ref.flat_grads(graph, params64)
+    c32 = float(np.dot(gf, g64) / (np.linalg.norm(gf) * np.linalg.norm(g64)))
+    assert c32 >= 0.9999, c32
+    assert np.linalg.norm(gf - g64) <= 1e-2 * np.linalg.norm(g64), np.linalg.norm(gf - g64) / np.linalg.norm(g64)
