@@ -294,6 +294,17 @@ int unet_conv3x3_bf16(const uint16_t *in, int in_ld, const uint16_t *w_packed, c
                       uint16_t *out, int out_ld, float *stat_partials, int N, int H, int W, int CiP, int CoP,
                       int accumulate, unet_stream_t stream);
 int unet_conv3x3_stat_tiles(int H, int W);
+/* Data gradient of a 3x3 convolution whose INPUT is the output of a BN + ReLU
+ * layer (fuses the first pass of cudaBatchNormBackward for that layer into the
+ * data-gradient half of cudaConvolveBackward).  dx = conv(dz, w_packed_bwd) is
+ * written (not accumulated), and red_partials receives [N][tiles][CoP][2]
+ * per-tile (sum g*xhat, sum g) with g = dx * relu'(a*z+b), where bn_z is that
+ * layer's pre-BN tensor and bn_coef its unet_bn_finalize_bf16 records; feed
+ * them to unet_bn_act_backward_from_partials_bf16. */
+int unet_conv3x3_dgrad_bnred_bf16(const uint16_t *dz, int dz_ld, const uint16_t *w_packed_bwd, uint16_t *dx,
+                                  int dx_ld, const uint16_t *bn_z, int bn_z_ld, const float *bn_coef,
+                                  float *red_partials, int N, int H, int W, int CiP, int CoP,
+                                  unet_stream_t stream);
 /* Weight-gradient half of cudaConvolveBackward: grad_w [Ci][Co][3][3] fp32
  * (overwritten) = sum over pixels of dz x shifted x.  Deterministic. */
 int unet_conv3x3_wgrad_bf16(const uint16_t *dz, int dz_ld, const uint16_t *x, int x_ld, float *grad_w, int N, int H,
@@ -307,6 +318,13 @@ int unet_tconv2x2_bf16(const uint16_t *in, int in_ld, const uint16_t *w_packed, 
                        unet_stream_t stream);
 int unet_tconv2x2_dgrad_bf16(const uint16_t *dy, int dy_ld, const uint16_t *w_packed_bwd, uint16_t *dx, int dx_ld,
                              int N, int H_in, int W_in, int CiP, int CoP, int accumulate, unet_stream_t stream);
+/* unet_tconv2x2_dgrad_bf16 (accumulate = 0) with the same fused BN-backward
+ * reduction as unet_conv3x3_dgrad_bnred_bf16; red_partials is
+ * [N][tiles(H_in, W_in)][CiP][2]. */
+int unet_tconv2x2_dgrad_bnred_bf16(const uint16_t *dy, int dy_ld, const uint16_t *w_packed_bwd, uint16_t *dx,
+                                   int dx_ld, const uint16_t *bn_z, int bn_z_ld, const float *bn_coef,
+                                   float *red_partials, int N, int H_in, int W_in, int CiP, int CoP,
+                                   unet_stream_t stream);
 int unet_tconv2x2_wgrad_bf16(const uint16_t *dy, int dy_ld, const uint16_t *x, int x_ld, float *grad_w, int N,
                              int H_in, int W_in, int CiP, int CoP, int Ci, int Co, unet_stream_t stream);
 
@@ -336,6 +354,15 @@ int unet_bn_act_bf16(const uint16_t *z, int z_ld, uint16_t *y, int y_ld, const f
 int unet_bn_act_backward_bf16(const uint16_t *dy1, int ld1, const uint16_t *dy2, int ld2, const uint16_t *z, int z_ld,
                               const float *coef, const float *gamma_beta, uint16_t *dz, int dz_ld, float *grad_gb,
                               float *grad_bias, int C, int CoP, int64_t pixels, int act, unet_stream_t stream);
+
+/* The same with the reduction pass already done by the kernel that produced
+ * dy (unet_conv3x3_dgrad_bnred_bf16 / unet_tconv2x2_dgrad_bnred_bf16):
+ * red_partials is [num_partials][CoP][2]; ReLU only. */
+int unet_bn_act_backward_from_partials_bf16(const uint16_t *dy, int dy_ld, const uint16_t *z, int z_ld,
+                                            const float *coef, const float *gamma_beta,
+                                            const float *red_partials, int num_partials, uint16_t *dz,
+                                            int dz_ld, float *grad_gb, float *grad_bias, int C, int CoP,
+                                            int64_t pixels, unet_stream_t stream);
 
 /* 2x2 stride-2 max pool on NHWC bf16 (cudaMaxPool) that also saves a tie mask:
  * mask[n,ho,wo,c] bit (2i+j) is set when x[n,2ho+i,2wo+j,c] equals the maximum.

@@ -289,3 +289,58 @@ def test_max_pool_bf16(G, capi, oracle, cfg):
     np.testing.assert_array_equal(nchw(dx, c), dx_ref)
     capi.unet_max_pool2x2_backward_bf16(G.p(dyt), c, G.p(mask), G.p(dx), c, n, h, w, c, 1, None)
     np.testing.assert_array_equal(nchw(dx, c), bf16_round(2 * dx_ref))
+
+
+@pytest.mark.parametrize("cfg", [("conv", 2, 64, 64, 24, 40), ("conv", 1, 32, 96, 16, 16), ("tconv", 2, 64, 32, 8, 12)])
+def test_dgrad_with_fused_bn_backward_reduction(G, capi, cfg):
+    """The data-gradient kernels that also reduce the parent's batch-norm backward over the pixels:
+    dx is bit-identical to the plain data gradient, and dz / dgamma / dbeta / dbias agree with the
+    separate reduce + apply path (same sums, different order of addition)."""
+    kind, n, cp, cn, h, w = cfg          # cp: parent's channels (= dx channels), cn: this layer's channels
+    rng = np.random.default_rng(11)
+    k = 3 if kind == "conv" else 2
+    hz, wz = (h, w) if kind == "conv" else (2 * h, 2 * w)
+    dzn = torch.from_numpy(rng.standard_normal((n, hz, wz, cn)).astype(np.float32)).to(G.DEV).bfloat16()
+    wflat = (rng.standard_normal(cp * cn * k * k + cn) * 0.1).astype(np.float32)
+    _, wb = pack(G, capi, wflat, cp, cn, k)
+    zp = torch.from_numpy(rng.standard_normal((n, h, w, cp)).astype(np.float32)).to(G.DEV).bfloat16()
+    # parent's BN records {a, b, mean, invb} and gamma/beta
+    gb = G.dev((rng.random(2 * cp) + 0.5).astype(np.float32))
+    coef_h = np.stack([rng.random(cp) + 0.5, rng.standard_normal(cp) * 0.3, rng.standard_normal(cp) * 0.1,
+                       rng.random(cp) + 0.7], axis=1).astype(np.float32)
+    coef = G.dev(coef_h.reshape(-1))
+    pixels = n * h * w
+    tiles = capi.lib().unet_conv3x3_stat_tiles(h, w)
+
+    def run(fused):
+        dx = torch.zeros((n, h, w, cp), dtype=torch.bfloat16, device=G.DEV)
+        dzp = torch.zeros((n, h, w, cp), dtype=torch.bfloat16, device=G.DEV)
+        ggb, gbias = G.empty((2 * cp,)), G.empty((cp,))
+        if fused:
+            parts = G.empty((n * tiles * cp * 2,))
+            if kind == "conv":
+                capi.unet_conv3x3_dgrad_bnred_bf16(G.p(dzn), cn, G.p(wb), G.p(dx), cp, G.p(zp), cp, G.p(coef), G.p(parts),
+                                                   n, h, w, cn, cp, None)
+            else:
+                capi.unet_tconv2x2_dgrad_bnred_bf16(G.p(dzn), cn, G.p(wb), G.p(dx), cp, G.p(zp), cp, G.p(coef),
+                                                    G.p(parts), n, h, w, cp, cn, None)
+            capi.unet_bn_act_backward_from_partials_bf16(G.p(dx), cp, G.p(zp), cp, G.p(coef), G.p(gb), G.p(parts),
+                                                         n * tiles, G.p(dzp), cp, G.p(ggb), G.p(gbias), cp, cp, pixels, None)
+        else:
+            if kind == "conv":
+                capi.unet_conv3x3_bf16(G.p(dzn), cn, G.p(wb), None, 0, G.p(dx), cp, None, n, h, w, cn, cp, 0, None)
+            else:
+                capi.unet_tconv2x2_dgrad_bf16(G.p(dzn), cn, G.p(wb), G.p(dx), cp, n, h, w, cp, cn, 0, None)
+            capi.unet_bn_act_backward_bf16(G.p(dx), cp, None, 0, G.p(zp), cp, G.p(coef), G.p(gb), G.p(dzp), cp, G.p(ggb),
+                                           G.p(gbias), cp, cp, pixels, 0, None)
+        torch.cuda.synchronize()
+        return dx.float().cpu().numpy(), dzp.float().cpu().numpy(), G.host(ggb), G.host(gbias)
+
+    dx_a, dz_a, ggb_a, gbias_a = run(False)
+    dx_b, dz_b, ggb_b, gbias_b = run(True)
+    assert np.abs(dx_a).max() > 0
+    np.testing.assert_array_equal(dx_a, dx_b)
+    assert_close(ggb_b, ggb_a, rtol=1e-4, atol_scale=1e-5, what="dgamma/dbeta")
+    assert_close(gbias_b, gbias_a, rtol=1e-3, atol_scale=1e-4, what="dbias")
+    # dz is bf16: the two paths may differ by one rounding where the fp32 value sits on a boundary
+    assert_close_bf16(dz_b, dz_a, what="dz")

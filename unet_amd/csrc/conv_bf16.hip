@@ -51,11 +51,17 @@ struct ConvArgs {
   int k_phases;          // 4: the reduction also runs over the input phases (data gradient); else 1
   i64 wt_phase_stride;   // elements between the packed weights of consecutive phases
   i64 stats_phase_stride;
+  // BRED kernels only (data gradient whose output is the gradient of a BN + ReLU layer's output):
+  // that layer's pre-BN tensor and per-channel records {a, b, mean, 1/sqrt(var+eps)}; `stats` then
+  // receives per-tile (sum g*xhat, sum g), g = dy * relu'(a*z + b).
+  const bf16_t *bz;
+  int bz_ld;
+  const float4 *bcf;
 };
 
 constexpr int PITCH = 80;  // bytes per LDS row of 32 bf16 (64 B payload + 16 B pad)
 
-template <int TAPS, int BN>
+template <int TAPS, int BN, bool BRED = false>
 __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
   constexpr int HALO = (TAPS == 9) ? 18 : 16;
   constexpr int NPIX = HALO * HALO;
@@ -161,6 +167,13 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
       }
     }
 
+  // BRED: the records of the 8 channels this thread will handle in the store pass
+  float4 bcf[BRED ? 8 : 1];
+  if (BRED) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bcf[j] = a.bcf[co0 + (tid % (BN / 8)) * 8 + j];
+  }
+
   const int nk = (TAPS == 1) ? nk1 * a.k_phases : nk1;
   load_chunk(0);
   store_chunk();
@@ -196,6 +209,22 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
   // ---- epilogue: accumulators -> bf16 staging tile [256 pixels][BN] in LDS ----
   constexpr int OP = BN * 2 + 16;  // staging row pitch in bytes
   unsigned char *stage = lds;
+  // BRED: this thread's pieces of the parent's pre-BN tensor, requested now so that they arrive
+  // while the accumulators are staged
+  constexpr int CHB = BN / 8;
+  uint4 zq[BRED ? CHB : 1];
+  if (BRED) {
+#pragma unroll
+    for (int i = 0; i < CHB; ++i) {
+      const int pix = tid / CHB + i * (256 / CHB);
+      const int y = y0 + (pix >> 4), x = x0 + (pix & 15);
+      zq[i] = make_uint4(0, 0, 0, 0);
+      if (y < a.Ho && x < a.Wo)
+        zq[i] = *reinterpret_cast<const uint4 *>(
+            a.bz + (n * (i64)a.Hout * a.Wout + (i64)(y * a.out_s + out_oy) * a.Wout + (x * a.out_s + out_ox)) * a.bz_ld +
+            co0 + (tid % CHB) * 8);
+    }
+  }
 #pragma unroll
   for (int m = 0; m < MF; ++m)
 #pragma unroll
@@ -226,7 +255,18 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
     const int y = y0 + (pix >> 4), x = x0 + (pix & 15);
     if (y < a.Ho && x < a.Wo) {
       uint4 v = *reinterpret_cast<const uint4 *>(stage + pix * OP + part * 16);
-      if (stats) {
+      if (BRED) {
+        const uint32_t vv[4] = {v.x, v.y, v.z, v.w}, zz[4] = {zq[i].x, zq[i].y, zq[i].z, zq[i].w};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const uint32_t vw = vv[j >> 1], zw = zz[j >> 1];
+          const float dy = (j & 1) ? bf16_to_f32(vw >> 16) : bf16_to_f32(vw & 0xffffu);
+          const float zv = (j & 1) ? bf16_to_f32(zw >> 16) : bf16_to_f32(zw & 0xffffu);
+          const float g = fmaf(bcf[j].x, zv, bcf[j].y) > 0.f ? dy : 0.f;
+          ssum[j] = fmaf(g, zv, ssum[j]);  // sum g*z; turned into sum g*xhat after the loop
+          ssq[j] += g;
+        }
+      } else if (stats) {
         const uint32_t vv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -251,7 +291,11 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
       *reinterpret_cast<uint4 *>(dst) = v;
     }
   }
-  if (stats) {
+  if (BRED) {  // sum g*xhat = (sum g*z - mean * sum g) / sqrt(var + eps)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ssum[j] = (ssum[j] - bcf[j].z * ssq[j]) * bcf[j].w;
+  }
+  if (BRED || stats) {
     // lanes with equal (lane % CH) hold the same 8 channels: butterfly over the other lane bits,
     // then one partial per wave through LDS, summed in wave order (deterministic)
 #pragma unroll
@@ -285,28 +329,33 @@ constexpr size_t conv_lds_bytes() {
   return main_loop > epilogue ? main_loop : epilogue;
 }
 
-template <int TAPS, int BN>
+template <int TAPS, int BN, bool BRED>
 int launch_conv(const ConvArgs &a, hipStream_t s) {
   static bool attr_set[64] = {};
   constexpr size_t lds = conv_lds_bytes<TAPS, BN>();
   int dev = 0;
   UNET_HIP_TRY(hipGetDevice(&dev));
   if (!attr_set[dev & 63]) {
-    UNET_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_mfma_kernel<TAPS, BN>),
+    UNET_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_mfma_kernel<TAPS, BN, BRED>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set[dev & 63] = true;
   }
   const int tilesY = (a.Ho + 15) / 16;
   dim3 grid((unsigned)(tilesY * a.tilesX), (unsigned)(a.CoP / BN * (a.out_phases > 1 ? a.out_phases : 1)),
             (unsigned)a.N);
-  hipLaunchKernelGGL((conv_mfma_kernel<TAPS, BN>), grid, dim3(256), lds, s, a);
+  hipLaunchKernelGGL((conv_mfma_kernel<TAPS, BN, BRED>), grid, dim3(256), lds, s, a);
   UNET_LAUNCH_CHECK("conv_mfma_kernel");
   return UNET_OK;
 }
 
 int launch_conv_any(int taps, const ConvArgs &a, hipStream_t s) {
-  if (taps == 9) return (a.CoP % 64 == 0) ? launch_conv<9, 64>(a, s) : launch_conv<9, 32>(a, s);
-  return (a.CoP % 64 == 0) ? launch_conv<1, 64>(a, s) : launch_conv<1, 32>(a, s);
+  const bool wide = a.CoP % 64 == 0;
+  if (a.bz) {
+    if (taps == 9) return wide ? launch_conv<9, 64, true>(a, s) : launch_conv<9, 32, true>(a, s);
+    return wide ? launch_conv<1, 64, true>(a, s) : launch_conv<1, 32, true>(a, s);
+  }
+  if (taps == 9) return wide ? launch_conv<9, 64, false>(a, s) : launch_conv<9, 32, false>(a, s);
+  return wide ? launch_conv<1, 64, false>(a, s) : launch_conv<1, 32, false>(a, s);
 }
 
 // ---------------------------------------------------------------------------
@@ -476,6 +525,30 @@ int unet_conv3x3_bf16(const uint16_t *in, int in_ld, const uint16_t *w_packed, c
 
 int unet_conv3x3_stat_tiles(int H, int W) { return ((H + 15) / 16) * ((W + 15) / 16); }
 
+int unet_conv3x3_dgrad_bnred_bf16(const uint16_t *dz, int dz_ld, const uint16_t *w_packed_bwd, uint16_t *dx,
+                                  int dx_ld, const uint16_t *bn_z, int bn_z_ld, const float *bn_coef,
+                                  float *red_partials, int N, int H, int W, int CiP, int CoP, unet_stream_t s) {
+  UNET_REQUIRE(dz && w_packed_bwd && dx && bn_z && bn_coef && red_partials, "unet_conv3x3_dgrad_bnred_bf16: NULL pointer");
+  UNET_REQUIRE(N > 0 && N <= 65535 && H > 0 && W > 0, "unet_conv3x3_dgrad_bnred_bf16: bad sizes");
+  UNET_REQUIRE(CiP > 0 && CiP % 32 == 0 && CoP > 0 && CoP % 32 == 0 && dz_ld >= CiP && dx_ld >= CoP &&
+                   bn_z_ld >= CoP && dz_ld % 8 == 0 && dx_ld % 8 == 0 && bn_z_ld % 8 == 0,
+               "unet_conv3x3_dgrad_bnred_bf16: channel counts must be multiples of 32 and pixel strides multiples of 8");
+  UNET_REQUIRE((((uintptr_t)dz | (uintptr_t)dx | (uintptr_t)w_packed_bwd | (uintptr_t)bn_z | (uintptr_t)bn_coef) & 15) == 0,
+               "unet_conv3x3_dgrad_bnred_bf16: pointers must be 16-byte aligned");
+  UNET_REQUIRE((i64)H * W * dz_ld < (1ll << 31) && (i64)H * W * dx_ld < (1ll << 31) && (i64)H * W * bn_z_ld < (1ll << 31),
+               "unet_conv3x3_dgrad_bnred_bf16: one image must stay below 2^31 elements");
+  ConvArgs a{};
+  a.in = dz; a.wt = w_packed_bwd; a.bias = nullptr; a.out = dx; a.stats = red_partials;
+  a.N = N; a.Hin = H; a.Win = W; a.Ho = H; a.Wo = W; a.Ci = CiP; a.CoP = CoP;
+  a.in_ld = dz_ld; a.out_ld = dx_ld; a.in_s = 1; a.out_s = 1; a.Hout = H; a.Wout = W;
+  a.tilesX = (W + 15) / 16;
+  a.out_phases = a.k_phases = 1;
+  a.bz = bn_z; a.bz_ld = bn_z_ld; a.bcf = reinterpret_cast<const float4 *>(bn_coef);
+  ProfScope prof(PROF_CONV_DGRAD_BF16, 2.0 * N * H * W * (double)CiP * CoP * 9,
+                 2.0 * N * H * W * ((double)CiP + 2.0 * CoP), as_stream(s));
+  return launch_conv_any(9, a, as_stream(s));
+}
+
 // One (i,j) phase launch per call is an implementation detail: these entry
 // points run all four phases of the 2x2 stride-2 transposed convolution.
 int unet_tconv2x2_bf16(const uint16_t *in, int in_ld, const uint16_t *w_packed, const float *bias, int co_valid,
@@ -524,6 +597,35 @@ int unet_tconv2x2_dgrad_bf16(const uint16_t *dy, int dy_ld, const uint16_t *w_pa
   a.tilesX = (W_in + 15) / 16;
   a.out_phases = 1; a.k_phases = 4;
   a.wt_phase_stride = (i64)CiP * CoP;
+  return launch_conv_any(1, a, as_stream(s));
+}
+
+int unet_tconv2x2_dgrad_bnred_bf16(const uint16_t *dy, int dy_ld, const uint16_t *w_packed_bwd, uint16_t *dx,
+                                   int dx_ld, const uint16_t *bn_z, int bn_z_ld, const float *bn_coef,
+                                   float *red_partials, int N, int H_in, int W_in, int CiP, int CoP,
+                                   unet_stream_t s) {
+  UNET_REQUIRE(dy && w_packed_bwd && dx && bn_z && bn_coef && red_partials,
+               "unet_tconv2x2_dgrad_bnred_bf16: NULL pointer");
+  UNET_REQUIRE(N > 0 && N <= 65535 && H_in > 0 && W_in > 0, "unet_tconv2x2_dgrad_bnred_bf16: bad sizes");
+  UNET_REQUIRE(CiP > 0 && CiP % 32 == 0 && CoP > 0 && CoP % 32 == 0 && dy_ld >= CoP && dx_ld >= CiP &&
+                   bn_z_ld >= CiP && dy_ld % 8 == 0 && dx_ld % 8 == 0 && bn_z_ld % 8 == 0,
+               "unet_tconv2x2_dgrad_bnred_bf16: channel counts must be multiples of 32 and pixel strides multiples of 8");
+  UNET_REQUIRE((((uintptr_t)dy | (uintptr_t)dx | (uintptr_t)w_packed_bwd | (uintptr_t)bn_z | (uintptr_t)bn_coef) & 15) == 0,
+               "unet_tconv2x2_dgrad_bnred_bf16: pointers must be 16-byte aligned");
+  UNET_REQUIRE((i64)4 * H_in * W_in * dy_ld < (1ll << 31) && (i64)H_in * W_in * dx_ld < (1ll << 31) &&
+                   (i64)H_in * W_in * bn_z_ld < (1ll << 31),
+               "unet_tconv2x2_dgrad_bnred_bf16: one image must stay below 2^31 elements");
+  ProfScope prof(PROF_TCONV_BF16, 2.0 * N * H_in * W_in * 4.0 * CiP * CoP,
+                 2.0 * N * H_in * W_in * (2.0 * CiP + 4.0 * CoP), as_stream(s));
+  ConvArgs a{};
+  a.in = dy; a.wt = w_packed_bwd; a.bias = nullptr; a.out = dx; a.stats = red_partials;
+  a.N = N; a.Hin = 2 * H_in; a.Win = 2 * W_in; a.Ho = H_in; a.Wo = W_in; a.Ci = CoP; a.CoP = CiP;
+  a.in_ld = dy_ld; a.out_ld = dx_ld; a.in_s = 2; a.in_oy = a.in_ox = 0;
+  a.out_s = 1; a.out_oy = a.out_ox = 0; a.Hout = H_in; a.Wout = W_in; a.accumulate = 0;
+  a.tilesX = (W_in + 15) / 16;
+  a.out_phases = 1; a.k_phases = 4;
+  a.wt_phase_stride = (i64)CiP * CoP;
+  a.bz = bn_z; a.bz_ld = bn_z_ld; a.bcf = reinterpret_cast<const float4 *>(bn_coef);
   return launch_conv_any(1, a, as_stream(s));
 }
 

@@ -568,6 +568,45 @@ int unet_bn_act_backward_bf16(const uint16_t *dy1, int ld1, const uint16_t *dy2,
   return UNET_OK;
 }
 
+int unet_bn_act_backward_from_partials_bf16(const uint16_t *dy, int dy_ld, const uint16_t *z, int z_ld,
+                                            const float *coef, const float *gamma_beta,
+                                            const float *red_partials, int num_partials, uint16_t *dz,
+                                            int dz_ld, float *grad_gb, float *grad_bias, int C, int CoP,
+                                            int64_t pixels, unet_stream_t s) {
+  int rc = check_view("unet_bn_act_backward_from_partials_bf16 (dy)", dy, dy_ld, CoP);
+  if (!rc) rc = check_view("unet_bn_act_backward_from_partials_bf16 (z)", z, z_ld, CoP);
+  if (!rc) rc = check_view("unet_bn_act_backward_from_partials_bf16 (dz)", dz, dz_ld, CoP);
+  if (rc) return rc;
+  UNET_REQUIRE(coef && gamma_beta && grad_gb && red_partials && num_partials > 0 && C > 0 && CoP >= C &&
+                   CoP % 8 == 0 && CoP <= 2048 && pixels > 0,
+               "unet_bn_act_backward_from_partials_bf16: bad argument (CoP must be a multiple of 8, at most 2048)");
+  const RedPlan pl = plan_reduce(CoP, pixels);
+  // workspace: ChanBwd [CoP] | bias partials [blocks][CoP]
+  const size_t n_cb = (size_t)CoP * 4, n_bias = (size_t)pl.blocks * CoP;
+  void *ws;
+  rc = unet_workspace(&ws, sizeof(float) * (n_cb + n_bias));
+  if (rc) return rc;
+  float *cbf = (float *)ws, *bias_part = cbf + n_cb;
+  const ChanFwd *cf = reinterpret_cast<const ChanFwd *>(coef);
+  ChanBwd *cb = reinterpret_cast<ChanBwd *>(cbf);
+  hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(cdiv_u(CoP, 4)), dim3(256), 0, as_stream(s), red_partials,
+                     num_partials, C, CoP, (float)pixels, gamma_beta, cf, grad_gb, cb);
+  UNET_LAUNCH_CHECK("bn_finalize_bwd_kernel");
+  {
+    ProfScope prof(PROF_BN_BWD_APPLY_BF16, 0, 2.0 * (double)pixels * CoP * 3.0, as_stream(s));
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<0>, dim3(pl.blocks), dim3(256), sizeof(float) * (size_t)pl.PL * pl.CG * 8,
+                       as_stream(s), dy, dy_ld, (const bf16_t *)nullptr, 0, z, z_ld, cf, (const ChanBwd *)cb, dz, dz_ld,
+                       pl.CG, pl.PL, (i64)pixels, pl.ppb, bias_part, CoP);
+  }
+  UNET_LAUNCH_CHECK("bn_bwd_apply_kernel");
+  if (grad_bias) {
+    hipLaunchKernelGGL(column_sum_kernel, dim3(cdiv_u(C, 4)), dim3(256), 0, as_stream(s), (const float *)bias_part,
+                       pl.blocks, C, CoP, grad_bias);
+    UNET_LAUNCH_CHECK("column_sum_kernel");
+  }
+  return UNET_OK;
+}
+
 int unet_max_pool2x2_bf16(const uint16_t *x, int x_ld, uint16_t *y, int y_ld, uint8_t *mask, int N, int H, int W,
                           int C, unet_stream_t s) {
   int rc = check_view("unet_max_pool2x2_bf16 (x)", x, x_ld, C);

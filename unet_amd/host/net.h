@@ -123,6 +123,8 @@ struct Node {
   DeviceBuffer coef;             // batch-norm coefficients of the last forward
   DeviceBuffer w_fwd, w_bwd;     // packed bf16 weights
   DeviceBuffer stat_partials;
+  DeviceBuffer bwd_partials;     // BN-backward sums emitted by the consumer's data-gradient kernel
+  int bwd_partials_n = 0;        // number of partial rows in it; 0 = none this step
   int concat_child = -1;         // index of the CONCAT consumer (at most one on this path)
   int concat_slot = 0;           // 0: first parent (skip), 1: second parent
   int64_t in_elems() const { return (int64_t)in_c * in_h * in_w; }
@@ -271,6 +273,7 @@ class Net {
       for (Node &n : nodes_) {
         n.g_written = false;
         n.g2_ptr = nullptr;
+        n.bwd_partials_n = 0;
       }
     for (int i = (int)nodes_.size() - 1; i >= 0; --i) {
       if (use_bf16_)
@@ -768,6 +771,7 @@ class Net {
         const size_t in_pix_tiles = (size_t)unet_conv3x3_stat_tiles(n.in_h, n.in_w);
         const size_t parts = n.type == CONV_LAYER ? b * in_pix_tiles : 4 * b * in_pix_tiles;
         n.stat_partials.ensure(sizeof(float) * parts * n.cop * 2);
+        n.bwd_partials.ensure(sizeof(float) * b * (size_t)unet_conv3x3_stat_tiles(n.out_h, n.out_w) * n.cop * 2);
         max_dz = std::max(max_dz, 2 * pix * n.cop);
         const size_t taps = n.type == CONV_LAYER ? 9 : 4;
         n.w_fwd.ensure(2 * taps * (size_t)n.cop * n.cip);
@@ -907,19 +911,40 @@ class Net {
           const uint16_t *d2 = (n.g_written && n.g2_ptr) ? n.g2_ptr : nullptr;
           if (!d1) return;  // not on a path to the loss
           const int act = (n.type == CONV_LAYER && n.activation == SIGMOID) ? 1 : 0;
-          UNET_CALL(unet_bn_act_backward_bf16(d1, l1, d2, n.g2_ld, n.zb.u16(), n.cop, n.coef.f32(), w + n.num_wb, dz,
-                                              n.cop, gw + n.num_wb, gbias, n.out_c, n.cop, out_pix, act, stream_));
+          if (n.bwd_partials_n > 0)  // the consumer's data-gradient kernel already reduced over the pixels
+            UNET_CALL(unet_bn_act_backward_from_partials_bf16(d1, l1, n.zb.u16(), n.cop, n.coef.f32(), w + n.num_wb,
+                                                              n.bwd_partials.f32(), n.bwd_partials_n, dz, n.cop,
+                                                              gw + n.num_wb, gbias, n.out_c, n.cop, out_pix, stream_));
+          else
+            UNET_CALL(unet_bn_act_backward_bf16(d1, l1, d2, n.g2_ld, n.zb.u16(), n.cop, n.coef.f32(), w + n.num_wb, dz,
+                                                n.cop, gw + n.num_wb, gbias, n.out_c, n.cop, out_pix, act, stream_));
         }
         const uint16_t *x = n.parents.empty() ? x16_.u16() : nodes_[n.parents[0]].y_ptr;
         const int x_ld = n.parents.empty() ? 32 : nodes_[n.parents[0]].y_ld;
         if (!n.parents.empty()) {
           Node &p = nodes_[n.parents[0]];
-          if (n.type == CONV_LAYER)
+          // When this is the only gradient the parent's output receives and the parent is a
+          // BN + ReLU layer, the data-gradient kernel also does the pixel reduction of the parent's
+          // batch-norm backward.
+          const bool fuse = p.has_params() && !p.narrow && p.num_children == 1 && p.concat_child < 0 && !p.g_written &&
+                            !(p.type == CONV_LAYER && p.activation == SIGMOID);
+          if (fuse) {
+            if (n.type == CONV_LAYER)
+              UNET_CALL(unet_conv3x3_dgrad_bnred_bf16(dz, n.cop, n.w_bwd.u16(), p.gb.u16(), p.cop, p.zb.u16(), p.cop,
+                                                      p.coef.f32(), p.bwd_partials.f32(), batch, n.in_h, n.in_w, n.cop,
+                                                      n.cip, stream_));
+            else
+              UNET_CALL(unet_tconv2x2_dgrad_bnred_bf16(dz, n.cop, n.w_bwd.u16(), p.gb.u16(), p.cop, p.zb.u16(), p.cop,
+                                                       p.coef.f32(), p.bwd_partials.f32(), batch, n.in_h, n.in_w, n.cip,
+                                                       n.cop, stream_));
+            p.bwd_partials_n = batch * unet_conv3x3_stat_tiles(n.in_h, n.in_w);
+          } else if (n.type == CONV_LAYER) {
             UNET_CALL(unet_conv3x3_bf16(dz, n.cop, n.w_bwd.u16(), nullptr, 0, p.gb.u16(), p.cop, nullptr, batch, n.in_h,
                                         n.in_w, n.cop, n.cip, p.g_written ? 1 : 0, stream_));
-          else
+          } else {
             UNET_CALL(unet_tconv2x2_dgrad_bf16(dz, n.cop, n.w_bwd.u16(), p.gb.u16(), p.cop, batch, n.in_h, n.in_w, n.cip,
                                                n.cop, p.g_written ? 1 : 0, stream_));
+          }
           p.g_written = true;
         }
         if (n.type == CONV_LAYER)
