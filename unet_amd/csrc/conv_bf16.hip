@@ -160,19 +160,13 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
     for (int g = 0; g < 4; ++g) {
       const int ch = co0 + m * 32 + 8 * g + 4 * (lane >> 5);
       bias_r[m][g] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (a.bias) {
+      if (!BRED && a.bias) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           if (ch + j < a.co_valid) bias_r[m][g][j] = a.bias[ch + j];
       }
     }
 
-  // BRED: the records of the 8 channels this thread will handle in the store pass
-  float4 bcf[BRED ? 8 : 1];
-  if (BRED) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) bcf[j] = a.bcf[co0 + (tid % (BN / 8)) * 8 + j];
-  }
 
   const int nk = (TAPS == 1) ? nk1 * a.k_phases : nk1;
   load_chunk(0);
@@ -213,7 +207,10 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
   // while the accumulators are staged
   constexpr int CHB = BN / 8;
   uint4 zq[BRED ? CHB : 1];
+  float4 bcf[BRED ? 8 : 1];  // BN records of the 8 channels this thread handles in the store pass
   if (BRED) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bcf[j] = a.bcf[co0 + (tid % CHB) * 8 + j];
 #pragma unroll
     for (int i = 0; i < CHB; ++i) {
       const int pix = tid / CHB + i * (256 / CHB);
@@ -234,7 +231,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
       for (int g = 0; g < 4; ++g) {
         const int ch = m * 32 + 8 * g + 4 * (lane >> 5);
         f32x4 v = {acc[m][q][4 * g], acc[m][q][4 * g + 1], acc[m][q][4 * g + 2], acc[m][q][4 * g + 3]};
-        v += bias_r[m][g];
+        if (!BRED) v += bias_r[m][g];
         const bf16x4 h = __builtin_convertvector(v, bf16x4);
         *reinterpret_cast<bf16x4 *>(stage + pix * OP + ch * 2) = h;
       }
