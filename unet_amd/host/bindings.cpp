@@ -53,10 +53,18 @@ class NN {
     for (int epoch = 0; epoch < epochs; ++epoch) {
       if (v) std::cout << "beggining epoch " << epoch << "/" << epochs << std::endl;
       const auto t0 = std::chrono::steady_clock::now();
+      // batch b+1 is staged (host copy to pinned memory, then an asynchronous transfer on a second
+      // stream) while the GPU runs batch b
+      net_.stage_batch_host(0, img, msk, (int)std::min<int64_t>(batch_size, N));
       for (int64_t b = 0; b < nb; ++b) {
         const int64_t start = b * batch_size;
         const int cur = (int)std::min<int64_t>(batch_size, N - start);
-        net_.train_batch_host(img + start * C * H * W, msk + start * H * W, cur, learning_rate, true);
+        net_.train_batch_staged((int)(b & 1), learning_rate, true);
+        if (b + 1 < nb) {
+          const int64_t nstart = start + batch_size;
+          net_.stage_batch_host((int)((b + 1) & 1), img + nstart * C * H * W, msk + nstart * H * W,
+                                (int)std::min<int64_t>(batch_size, N - nstart));
+        }
         if (net_.loss() == LossFunction::kDiceLoss)
           UNET_CALL(unet_memcpy_d2d(epoch_lv.f32() + 3 * (size_t)batch_size * b, net_.loss_values_ptr(),
                                     sizeof(float) * 3 * cur, net_.stream()));

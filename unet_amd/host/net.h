@@ -137,6 +137,12 @@ class Net {
   Net() = default;
   ~Net() {
     for (void *e : bucket_events_) unet_event_destroy(e);
+    for (InputSlot &sl : slots_) {
+      if (sl.pinned) unet_host_free(sl.pinned);
+      if (sl.copied) unet_event_destroy(sl.copied);
+      if (sl.consumed) unet_event_destroy(sl.consumed);
+    }
+    if (copy_stream_) unet_stream_destroy(copy_stream_);
   }
 
   // ---- graph construction (neural_net.h:72-120, layer.h:412-616) ----------
@@ -307,6 +313,52 @@ class Net {
     loss_forward_device(in_masks_.f32(), batch);
     backward_device(in_images_.f32(), in_masks_.f32(), batch);
     if (do_step) step_device(lr);
+  }
+
+  // ---- double-buffered input feed for train(): while the GPU works on batch b, the host copies
+  // batch b+1 into pinned memory and a second stream moves it to the device (the reference copies
+  // each batch from pageable memory on the compute stream, neural_net.h:160-166).
+  void stage_batch_host(int slot, const float *images, const float *masks, int batch) {
+    ensure_batch(batch);
+    InputSlot &sl = slots_[slot & 1];
+    const size_t ib = sizeof(float) * (size_t)batch * in_c_ * in_h_ * in_w_;
+    const Node &f = nodes_[final_];
+    const size_t mb = sizeof(float) * (size_t)batch * f.out_h * f.out_w;
+    if (!copy_stream_) UNET_CALL(unet_stream_create(&copy_stream_));
+    if (!sl.copied) {
+      UNET_CALL(unet_event_create(&sl.copied));
+      UNET_CALL(unet_event_create(&sl.consumed));
+    }
+    if (sl.pinned_bytes < ib + mb) {
+      if (sl.pinned) {
+        UNET_CALL(unet_event_synchronize(sl.copied));
+        UNET_CALL(unet_host_free(sl.pinned));
+      }
+      UNET_CALL(unet_host_malloc(&sl.pinned, ib + mb));
+      sl.pinned_bytes = ib + mb;
+    }
+    sl.images.ensure(ib);
+    sl.masks.ensure(mb);
+    if (sl.in_use) UNET_CALL(unet_event_synchronize(sl.copied));  // the pinned buffer is free again
+    std::memcpy(sl.pinned, images, ib);
+    std::memcpy(static_cast<char *>(sl.pinned) + ib, masks, mb);
+    if (sl.in_use) UNET_CALL(unet_stream_wait_event(copy_stream_, sl.consumed));  // device buffers no longer read
+    UNET_CALL(unet_memcpy_h2d(sl.images.raw(), sl.pinned, ib, copy_stream_));
+    UNET_CALL(unet_memcpy_h2d(sl.masks.raw(), static_cast<char *>(sl.pinned) + ib, mb, copy_stream_));
+    UNET_CALL(unet_event_record(sl.copied, copy_stream_));
+    sl.in_use = true;
+    sl.batch = batch;
+  }
+  // One training step on a staged batch; returns the device pointer of its masks' loss sums owner.
+  void train_batch_staged(int slot, float lr, bool do_step) {
+    InputSlot &sl = slots_[slot & 1];
+    if (!sl.in_use) throw std::runtime_error("train_batch_staged: the slot holds no batch");
+    UNET_CALL(unet_stream_wait_event(stream_, sl.copied));
+    forward_device(sl.images.f32(), sl.batch, false);
+    loss_forward_device(sl.masks.f32(), sl.batch);
+    backward_device(sl.images.f32(), sl.masks.f32(), sl.batch);
+    if (do_step) step_device(lr);
+    UNET_CALL(unet_event_record(sl.consumed, stream_));
   }
 
   // Loss of the last batch (synchronises): Dice: 1 - mean dice; difference:
@@ -976,6 +1028,17 @@ class Net {
         throw std::runtime_error("unsupported layer type in backward");
     }
   }
+
+  struct InputSlot {
+    void *pinned = nullptr;
+    size_t pinned_bytes = 0;
+    DeviceBuffer images, masks;
+    unet_event_t copied = nullptr, consumed = nullptr;
+    bool in_use = false;
+    int batch = 0;
+  };
+  InputSlot slots_[2];
+  unet_stream_t copy_stream_ = nullptr;
 
   std::vector<Node> nodes_;
   LossFunction loss_ = LossFunction::kDiceLoss;
