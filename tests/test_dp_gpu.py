@@ -121,3 +121,61 @@ def test_two_ranks_on_one_gpu_match_single_process():
     scale = np.abs(want).max()
     assert np.abs(g_a - want).max() <= 1e-6 * scale + 1e-12, np.abs(g_a - want).max() / scale
     assert np.isfinite(p1_a).all() and not np.array_equal(p1_a, p0_a)
+
+
+def _rccl_rank(port, q):
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        import torch
+        import torch.distributed as dist
+        from unet_amd import capi, dp
+        torch.cuda.set_device(0)
+        capi.unet_set_device(0)
+        dev = torch.device("cuda", 0)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        x, m = _data()
+        xs, ms = torch.from_numpy(x).to(dev), torch.from_numpy(m).to(dev)
+        plain = _make_net(64 << 10)
+        p0 = plain.get_parameters()
+        plain.forward_backward_device(xs.data_ptr(), ms.data_ptr(), BATCH)
+        plain.step(1e-3)
+        plain.synchronize()
+        want_g, want_p = np.asarray(plain.get_gradients()), np.asarray(plain.get_parameters())
+        net = _make_net(64 << 10)
+        net.set_parameters(p0)
+        trainer = dp.DataParallel(net, dev, bucket_bytes=64 << 10, force_collectives=True)
+        trainer.broadcast_parameters()
+        for _ in range(2):   # twice: the second pass reuses the bucket events and the communication stream
+            net.set_parameters(p0)
+            trainer.train_step(xs.data_ptr(), ms.data_ptr(), BATCH, 1e-3)
+            net.synchronize()
+            torch.cuda.synchronize()
+        got_g, got_p = np.asarray(net.get_gradients()), np.asarray(net.get_parameters())
+        dist.destroy_process_group()
+        q.put((True, (want_g, got_g, want_p, got_p, len(trainer.buckets))))
+    except Exception as e:
+        import traceback
+        q.put((False, traceback.format_exc() + str(e)))
+
+
+def test_rccl_transport_one_rank():
+    """The RCCL code path itself (communication stream, bucket events, asynchronous all-reduce with
+    AVG, the wait before the optimiser step) on a one-rank communicator: the mean over one rank must
+    leave the gradients and the update unchanged."""
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_rank, args=(port, q))
+    p.start()
+    ok, payload = q.get(timeout=240)
+    p.join(timeout=60)
+    assert ok, payload
+    want_g, got_g, want_p, got_p, nb = payload
+    assert nb >= 3
+    # the second step starts from the first step's Adam state, so compare gradients (state-free)
+    assert np.array_equal(want_g, got_g)
+    assert np.isfinite(got_p).all()

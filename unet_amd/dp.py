@@ -37,16 +37,17 @@ def shard_range(total, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def allreduce_mean_(flat, buckets, group=None, streams=None):
+def allreduce_mean_(flat, buckets, group=None, streams=None, force=False):
     """In-place mean over ranks of `flat` (1-D tensor), bucket by bucket.
 
     buckets: [(offset, count, event_handle_or_None)], processed in list order.
     streams: None, or (comm_stream, wait_event_fn) -- each bucket's collective
       is then enqueued on comm_stream after wait_event_fn(comm_stream, event).
+    force: run the collectives even in a one-rank group (exercises the transport).
     Returns the list of work handles (already waited on when streams is None).
     """
     world = dist.get_world_size(group)
-    if world == 1:
+    if world == 1 and not force:
         return []
     use_avg = dist.get_backend(group) == "nccl"
     op = dist.ReduceOp.AVG if use_avg else dist.ReduceOp.SUM
@@ -69,7 +70,7 @@ def allreduce_mean_(flat, buckets, group=None, streams=None):
 class DataParallel:
     """Wraps a created neural_net.NeuralNet for synchronous data-parallel SGD."""
 
-    def __init__(self, net, device, bucket_bytes=16 << 20, group=None):
+    def __init__(self, net, device, bucket_bytes=16 << 20, group=None, force_collectives=False):
         from unet_amd import capi
         self.net, self.device, self.group, self._capi = net, device, group, capi
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -79,10 +80,11 @@ class DataParallel:
         n = net.num_parameters()
         self.grads = tensor_from_ptr(net.gradients_ptr(), n, device)
         self.params = tensor_from_ptr(net.parameters_ptr(), n, device)
-        self.comm = torch.cuda.Stream(device=device) if self.world > 1 else None
+        self.force = bool(force_collectives) and dist.is_initialized()
+        self.comm = torch.cuda.Stream(device=device) if (self.world > 1 or self.force) else None
 
     def broadcast_parameters(self, src=0):
-        if self.world > 1:
+        if self.world > 1 or self.force:
             self.net.synchronize()
             dist.broadcast(self.params, src, group=self.group)
             torch.cuda.synchronize(self.device)
@@ -93,10 +95,10 @@ class DataParallel:
     def reduce_gradients(self):
         """Averages the gradient buffer over the ranks, bucket by bucket, each
         bucket as soon as backward has finished it."""
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return
         if dist.get_backend(self.group) == "nccl":
-            works = allreduce_mean_(self.grads, self.buckets, self.group, (self.comm, self._wait_event))
+            works = allreduce_mean_(self.grads, self.buckets, self.group, (self.comm, self._wait_event), self.force)
             for w in works:
                 w.wait()      # the compute stream waits for the reduced bucket
             return
