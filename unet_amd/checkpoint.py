@@ -1,0 +1,132 @@
+"""Checkpoints and PyTorch weight exchange for a created neural_net.NeuralNet.
+
+The reference cannot persist a trained model (src/neural_net.h keeps everything
+in device memory until exit); this module adds that on top of the module's
+parameter getters/setters.
+
+Parameter vector layout (the reference's per-layer order, src/layer.h:445-447):
+per CONV / UPSAMPLING layer  [ W (C_in, C_out, k, k) | bias (C_out) | gamma0, beta0, gamma1, beta1, ... ].
+Running statistics per layer: [mean0, var0, mean1, var1, ...].
+
+  save(net, path) / load(net, path)         .npz with parameters, running statistics, Adam state
+  to_torch(net)   -> {"layers.<i>.conv.weight": ..., ...}   tensors in PyTorch's layouts
+  from_torch(net, state)                    the inverse
+
+PyTorch layouts: nn.Conv2d weight is (C_out, C_in, k, k) -- transposed with
+respect to the reference; nn.ConvTranspose2d weight is (C_in, C_out, k, k) --
+the same; BatchNorm2d keeps weight (gamma), bias (beta), running_mean,
+running_var as separate vectors.
+"""
+import numpy as np
+
+FORMAT_VERSION = 1
+
+
+def _layers(net):
+    """[(layer index, parameter offset, number of weights+biases, number of BN params, output shape)]"""
+    shapes = net.output_shapes()
+    return [(i, off, nwb, nbn, shapes[i]) for i, off, nwb, nbn in net.parameter_layout()]
+
+
+def split_parameters(flat, layout):
+    """flat vector -> {layer: dict(wb=..., gamma=..., beta=...)} (views into a copy)."""
+    flat = np.asarray(flat, dtype=np.float32)
+    out = {}
+    for i, off, nwb, nbn in layout:
+        bn = flat[off + nwb:off + nwb + nbn]
+        out[i] = {"wb": flat[off:off + nwb].copy(), "gamma": bn[0::2].copy(), "beta": bn[1::2].copy()}
+    return out
+
+
+def save(net, path, include_optimizer=True):
+    """Writes parameters, running statistics and (optionally) the Adam state to `path` (.npz)."""
+    layout = net.parameter_layout()
+    arrays = {
+        "format_version": np.int64(FORMAT_VERSION),
+        "parameters": np.asarray(net.get_parameters(), dtype=np.float32),
+        "layout": np.asarray(layout, dtype=np.int64).reshape(-1, 4),
+    }
+    for i, _, _, nbn in layout:
+        if nbn:
+            arrays[f"running_{i}"] = np.asarray(net.running_stats(i), dtype=np.float32)
+    if include_optimizer:
+        arrays["adam_state"] = np.asarray(net.get_optimizer_state(), dtype=np.float32)
+        arrays["adam_steps"] = np.int64(net.optimizer_steps())
+    np.savez(path, **arrays)
+
+
+def load(net, path, include_optimizer=True):
+    """Restores what save() wrote into a network created from the same layer list."""
+    with np.load(path, allow_pickle=False) as f:
+        if int(f["format_version"]) != FORMAT_VERSION:
+            raise RuntimeError(f"unsupported checkpoint version {int(f['format_version'])}")
+        layout = np.asarray(net.parameter_layout(), dtype=np.int64).reshape(-1, 4)
+        if f["layout"].shape != layout.shape or not np.array_equal(f["layout"], layout):
+            raise RuntimeError("the checkpoint was written by a network with a different layer list")
+        net.set_parameters(np.ascontiguousarray(f["parameters"], dtype=np.float32))
+        for i, _, _, nbn in layout:
+            if nbn:
+                net.set_running_stats(int(i), np.ascontiguousarray(f[f"running_{int(i)}"], dtype=np.float32))
+        if include_optimizer and "adam_state" in f.files:
+            net.set_optimizer_state(np.ascontiguousarray(f["adam_state"], dtype=np.float32), int(f["adam_steps"]))
+
+
+def layer_to_torch(wb, c_in, c_out, k, transposed):
+    """[W (C_in,C_out,k,k) | bias] -> (weight in PyTorch's layout, bias)."""
+    nw = c_in * c_out * k * k
+    w = np.asarray(wb[:nw], dtype=np.float32).reshape(c_in, c_out, k, k)
+    if not transposed:              # nn.Conv2d wants (C_out, C_in, k, k)
+        w = w.transpose(1, 0, 2, 3)
+    return np.ascontiguousarray(w), np.asarray(wb[nw:nw + c_out], dtype=np.float32).copy()
+
+
+def layer_from_torch(weight, bias, transposed):
+    """PyTorch (weight, bias) -> [W (C_in,C_out,k,k) | bias] flat."""
+    w = np.asarray(weight, dtype=np.float32)
+    if not transposed:
+        w = w.transpose(1, 0, 2, 3)
+    return np.concatenate([np.ascontiguousarray(w).reshape(-1), np.asarray(bias, dtype=np.float32).reshape(-1)])
+
+
+def to_torch(net, descs):
+    """descs: the LayerDesc list the network was created from.  Returns numpy arrays keyed like a
+    PyTorch state_dict: layers.<i>.conv.{weight,bias}, layers.<i>.bn.{weight,bias,running_mean,running_var}."""
+    flat = np.asarray(net.get_parameters(), dtype=np.float32)
+    parts = split_parameters(flat, net.parameter_layout())
+    out = {}
+    for i, p in parts.items():
+        shape = list(descs[i].shape)
+        transposed = len(shape) == 5            # UPSAMPLING: [H, W, C_in, C_out, scale]
+        c_in, c_out, k = shape[2], shape[3], shape[4]
+        w, b = layer_to_torch(p["wb"], c_in, c_out, k, transposed)
+        r = np.asarray(net.running_stats(i), dtype=np.float32)
+        out[f"layers.{i}.conv.weight"] = w
+        out[f"layers.{i}.conv.bias"] = b
+        out[f"layers.{i}.bn.weight"] = p["gamma"]
+        out[f"layers.{i}.bn.bias"] = p["beta"]
+        out[f"layers.{i}.bn.running_mean"] = r[0::2].copy()
+        out[f"layers.{i}.bn.running_var"] = r[1::2].copy()
+    return out
+
+
+def from_torch(net, descs, state):
+    """Inverse of to_torch(); `state` maps the same keys to arrays / tensors."""
+    def arr(v):
+        return v.detach().cpu().numpy() if hasattr(v, "detach") else np.asarray(v)
+    flat = np.asarray(net.get_parameters(), dtype=np.float32).copy()
+    for i, off, nwb, nbn in net.parameter_layout():
+        shape = list(descs[i].shape)
+        transposed = len(shape) == 5
+        wb = layer_from_torch(arr(state[f"layers.{i}.conv.weight"]), arr(state[f"layers.{i}.conv.bias"]), transposed)
+        if wb.size != nwb:
+            raise RuntimeError(f"layer {i}: expected {nwb} weights and biases, got {wb.size}")
+        flat[off:off + nwb] = wb
+        bn = np.empty(nbn, np.float32)
+        bn[0::2] = arr(state[f"layers.{i}.bn.weight"])
+        bn[1::2] = arr(state[f"layers.{i}.bn.bias"])
+        flat[off + nwb:off + nwb + nbn] = bn
+        r = np.empty(nbn, np.float32)
+        r[0::2] = arr(state[f"layers.{i}.bn.running_mean"])
+        r[1::2] = arr(state[f"layers.{i}.bn.running_var"])
+        net.set_running_stats(int(i), r)
+    net.set_parameters(flat)

@@ -181,6 +181,23 @@ class NN {
     if (n.num_bn) net_.copy_running_stats_to_host(layer, a.mutable_data());
     return a;
   }
+  void set_running_stats(int layer, farray stats) {
+    const unet::Node &n = net_.nodes().at(layer);
+    py::buffer_info bi = stats.request();
+    if (bi.size != n.num_bn) throw std::runtime_error("set_running_stats: expected " + std::to_string(n.num_bn) + " values");
+    if (n.num_bn) net_.copy_running_stats_from_host(layer, static_cast<const float *>(bi.ptr));
+  }
+  py::array_t<float> get_optimizer_state() {
+    py::array_t<float> a((py::ssize_t)(2 * net_.num_parameters()));
+    net_.copy_optimizer_state_to_host(a.mutable_data());
+    return a;
+  }
+  void set_optimizer_state(farray state, int step_count) {
+    py::buffer_info bi = state.request();
+    if (bi.size != 2 * net_.num_parameters()) throw std::runtime_error("set_optimizer_state: wrong length");
+    net_.copy_optimizer_state_from_host(static_cast<const float *>(bi.ptr), step_count);
+  }
+  int optimizer_steps() const { return net_.step_count(); }
   // forward + loss + backward (+ Adam step when lr > 0 ... see do_step); returns the loss
   float train_step(farray images, farray masks, float learning_rate, bool do_step) {
     py::buffer_info ii = images.request(), mi = masks.request();
@@ -350,6 +367,10 @@ PYBIND11_MODULE(neural_net, m) {
       .def("forward", &NN::forward, py::arg("images"), py::arg("inference") = false)
       .def("layer_output", &NN::layer_output)
       .def("running_stats", &NN::running_stats)
+      .def("set_running_stats", &NN::set_running_stats)
+      .def("get_optimizer_state", &NN::get_optimizer_state)
+      .def("set_optimizer_state", &NN::set_optimizer_state)
+      .def("optimizer_steps", &NN::optimizer_steps)
       .def("train_step", &NN::train_step, py::arg("images"), py::arg("masks"), py::arg("learning_rate"),
            py::arg("do_step") = true)
       .def("reserve", &NN::reserve)

@@ -413,6 +413,21 @@ class Net {
     UNET_CALL(unet_memcpy_d2h(dst, n.running.raw(), sizeof(float) * (size_t)n.num_bn, 1, stream_));
   }
 
+  void copy_running_stats_from_host(int layer, const float *src) {
+    const Node &n = nodes_.at(layer);
+    UNET_CALL(unet_memcpy_h2d(n.running.raw(), src, sizeof(float) * (size_t)n.num_bn, stream_));
+    sync();
+  }
+  // Adam state ([m,v] interleaved per parameter) and step count, for checkpoints.
+  void copy_optimizer_state_to_host(float *dst) {
+    UNET_CALL(unet_memcpy_d2h(dst, adam_.raw(), 2 * sizeof(float) * (size_t)total_params_, 1, stream_));
+  }
+  void copy_optimizer_state_from_host(const float *src, int step_count) {
+    UNET_CALL(unet_memcpy_h2d(adam_.raw(), src, 2 * sizeof(float) * (size_t)total_params_, stream_));
+    sync();
+    step_count_ = step_count;
+  }
+
   // ---- data-parallel support ---------------------------------------------------
   // Gradient buckets: contiguous slices of the flat gradient buffer, cut at
   // layer boundaries, numbered in the order backward completes them (last layer
