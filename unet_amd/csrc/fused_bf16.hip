@@ -44,26 +44,27 @@ struct ChanBwd {
   float c0, k1, k2, pad;  // dz = c0*(g - k1 - xhat*k2): c0 = gamma*invb, k1 = dbeta/M, k2 = dgamma/M
 };
 
-// Sums column pairs (2c, 2c+1) of partials [P][CoP][2] with one wavefront per
-// channel: lanes stride over the P partials, accumulate in double and combine
-// with xor shuffles (fixed order, so the result is reproducible).
-__device__ __forceinline__ void wave_sum_partials(const float *__restrict__ partials, int P, int CoP, int c,
-                                                   double &s, double &q) {
-  const int lane = threadIdx.x & 63;
+// Sums column pair (2c, 2c+1) of partials [P][CoP][2] with one workgroup of 256 threads per
+// channel: threads stride over the P partials with eight independent loads in flight, accumulate
+// in double, combine with xor shuffles and a fixed-order sum over the four wavefronts
+// (reproducible).  Every thread of the workgroup returns the totals.
+__device__ __forceinline__ void block_sum_partials(const float *__restrict__ partials, int P, int CoP, int c,
+                                                    double &s, double &q) {
+  __shared__ double red[2][4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   double a = 0, b = 0;
-  int p = lane;
-  // eight independent strided loads in flight per lane
-  for (; p + 7 * 64 < P; p += 8 * 64) {
+  int p = tid;
+  for (; p + 7 * 256 < P; p += 8 * 256) {
     float2 v[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float2 *>(partials + ((i64)(p + u * 64) * CoP + c) * 2);
+    for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float2 *>(partials + ((i64)(p + u * 256) * CoP + c) * 2);
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       a += v[u].x;
       b += v[u].y;
     }
   }
-  for (; p < P; p += 64) {
+  for (; p < P; p += 256) {
     const float2 v = *reinterpret_cast<const float2 *>(partials + ((i64)p * CoP + c) * 2);
     a += v.x;
     b += v.y;
@@ -73,8 +74,13 @@ __device__ __forceinline__ void wave_sum_partials(const float *__restrict__ part
     a += __shfl_xor(a, o, 64);
     b += __shfl_xor(b, o, 64);
   }
-  s = a;
-  q = b;
+  if (lane == 0) {
+    red[0][wave] = a;
+    red[1][wave] = b;
+  }
+  __syncthreads();
+  s = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+  q = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
 }
 
 // partials [P][CoP][2] (sum, sum of squares) -> batch_stats, running stats, ChanFwd
@@ -83,16 +89,15 @@ __global__ __launch_bounds__(256) void bn_finalize_fwd_kernel(const float *__res
                                                               float *__restrict__ batch_stats,
                                                               float *__restrict__ running,
                                                               ChanFwd *__restrict__ out) {
-  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (c >= CoP) return;
+  const int c = blockIdx.x;  // one workgroup per channel
   ChanFwd r{0.f, 0.f, 0.f, 0.f};
   if (c < C) {
     double s, q;
-    wave_sum_partials(partials, P, CoP, c, s, q);
+    block_sum_partials(partials, P, CoP, c, s, q);
     const float mean = (float)(s / M);
     float var = (float)(q / M - (s / M) * (s / M));
     var = var < 0.f ? 0.f : var;
-    if ((threadIdx.x & 63) == 0) {
+    if (threadIdx.x == 0) {
       batch_stats[2 * c] = (float)s;
       batch_stats[2 * c + 1] = (float)q;
       if (running) {
@@ -105,7 +110,7 @@ __global__ __launch_bounds__(256) void bn_finalize_fwd_kernel(const float *__res
     r.mean = mean;
     r.invb = 1.0f / sqrtf(var + BN_EPS);
   }
-  if ((threadIdx.x & 63) == 0) out[c] = r;
+  if (threadIdx.x == 0) out[c] = r;
 }
 
 // inference: a, b from the running statistics
@@ -253,13 +258,12 @@ __global__ __launch_bounds__(256) void bn_finalize_bwd_kernel(const float *__res
                                                               int CoP, float M, const float *__restrict__ gb,
                                                               const ChanFwd *__restrict__ cf,
                                                               float *__restrict__ grad_gb, ChanBwd *__restrict__ out) {
-  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (c >= CoP) return;
+  const int c = blockIdx.x;  // one workgroup per channel
   ChanBwd r{0.f, 0.f, 0.f, 0.f};
   if (c < C) {
     double dg, db;
-    wave_sum_partials(partials, P, CoP, c, dg, db);
-    if ((threadIdx.x & 63) == 0) {
+    block_sum_partials(partials, P, CoP, c, dg, db);
+    if (threadIdx.x == 0) {
       grad_gb[2 * c] = (float)dg;
       grad_gb[2 * c + 1] = (float)db;
     }
@@ -267,7 +271,7 @@ __global__ __launch_bounds__(256) void bn_finalize_bwd_kernel(const float *__res
     r.k1 = (float)(db / M);
     r.k2 = (float)(dg / M);
   }
-  if ((threadIdx.x & 63) == 0) out[c] = r;
+  if (threadIdx.x == 0) out[c] = r;
 }
 
 // pass 2: dz = c0*(g - k1 - xhat*k2) (bf16) and per-block sums of dz (bias gradient)
@@ -349,25 +353,27 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16_t *__restr
   }
 }
 
-// out[c] = sum_p partial[p][c], c < C: one wavefront per channel
+// out[c] = sum_p partial[p][c], c < C: one workgroup per channel
 __global__ __launch_bounds__(256) void column_sum_kernel(const float *__restrict__ partial, int P, int C, int stride,
                                                          float *__restrict__ out) {
-  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (c >= C) return;
-  const int lane = threadIdx.x & 63;
+  __shared__ double red[4];
+  const int c = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   double s = 0;
-  int p = lane;
-  for (; p + 7 * 64 < P; p += 8 * 64) {
-    float v[8];
+  int p = tid;
+  for (; p + 3 * 256 < P; p += 4 * 256) {
+    float v[4];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = partial[(i64)(p + u * 64) * stride + c];
+    for (int u = 0; u < 4; ++u) v[u] = partial[(i64)(p + u * 256) * stride + c];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) s += v[u];
+    for (int u = 0; u < 4; ++u) s += v[u];
   }
-  for (; p < P; p += 64) s += partial[(i64)p * stride + c];
+  for (; p < P; p += 256) s += partial[(i64)p * stride + c];
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-  if (lane == 0) out[c] = (float)s;
+  if (lane == 0) red[wave] = s;
+  __syncthreads();
+  if (tid == 0) out[c] = (float)((red[0] + red[1]) + (red[2] + red[3]));
 }
 
 // ---- 2x2 / stride 2 max pool -------------------------------------------------------
@@ -478,7 +484,7 @@ int unet_bn_finalize_bf16(const float *stat_partials, int num_partials, int C, i
                           unet_stream_t s) {
   UNET_REQUIRE(stat_partials && gamma_beta && batch_stats && coef, "unet_bn_finalize_bf16: NULL pointer");
   UNET_REQUIRE(num_partials > 0 && C > 0 && CoP >= C && count > 0, "unet_bn_finalize_bf16: bad sizes");
-  hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(cdiv_u(CoP, 4)), dim3(256), 0, as_stream(s), stat_partials,
+  hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(CoP), dim3(256), 0, as_stream(s), stat_partials,
                      num_partials, C, CoP, (float)count, gamma_beta, batch_stats, running_stats,
                      reinterpret_cast<ChanFwd *>(coef));
   UNET_LAUNCH_CHECK("bn_finalize_fwd_kernel");
@@ -545,7 +551,7 @@ int unet_bn_act_backward_bf16(const uint16_t *dy1, int ld1, const uint16_t *dy2,
                          dy2, ld2, z, z_ld, cf, pl.CG, pl.PL, (i64)pixels, pl.ppb, partial, CoP);                   \
     }                                                                                                               \
     UNET_LAUNCH_CHECK("bn_bwd_reduce_kernel");                                                                      \
-    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(cdiv_u(CoP, 4)), dim3(256), 0, as_stream(s),                    \
+    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(CoP), dim3(256), 0, as_stream(s),                    \
                        (const float *)partial, pl.blocks, C, CoP, (float)pixels, gamma_beta, cf, grad_gb, cb);      \
     UNET_LAUNCH_CHECK("bn_finalize_bwd_kernel");                                                                    \
     {                                                                                                               \
@@ -561,7 +567,7 @@ int unet_bn_act_backward_bf16(const uint16_t *dy1, int ld1, const uint16_t *dy2,
   else BWD_LAUNCH(2);
 #undef BWD_LAUNCH
   if (grad_bias) {
-    hipLaunchKernelGGL(column_sum_kernel, dim3(cdiv_u(C, 4)), dim3(256), 0, as_stream(s), (const float *)bias_part,
+    hipLaunchKernelGGL(column_sum_kernel, dim3(C), dim3(256), 0, as_stream(s), (const float *)bias_part,
                        pl.blocks, C, CoP, grad_bias);
     UNET_LAUNCH_CHECK("column_sum_kernel");
   }
@@ -589,7 +595,7 @@ int unet_bn_act_backward_from_partials_bf16(const uint16_t *dy, int dy_ld, const
   float *cbf = (float *)ws, *bias_part = cbf + n_cb;
   const ChanFwd *cf = reinterpret_cast<const ChanFwd *>(coef);
   ChanBwd *cb = reinterpret_cast<ChanBwd *>(cbf);
-  hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(cdiv_u(CoP, 4)), dim3(256), 0, as_stream(s), red_partials,
+  hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(CoP), dim3(256), 0, as_stream(s), red_partials,
                      num_partials, C, CoP, (float)pixels, gamma_beta, cf, grad_gb, cb);
   UNET_LAUNCH_CHECK("bn_finalize_bwd_kernel");
   {
@@ -600,7 +606,7 @@ int unet_bn_act_backward_from_partials_bf16(const uint16_t *dy, int dy_ld, const
   }
   UNET_LAUNCH_CHECK("bn_bwd_apply_kernel");
   if (grad_bias) {
-    hipLaunchKernelGGL(column_sum_kernel, dim3(cdiv_u(C, 4)), dim3(256), 0, as_stream(s), (const float *)bias_part,
+    hipLaunchKernelGGL(column_sum_kernel, dim3(C), dim3(256), 0, as_stream(s), (const float *)bias_part,
                        pl.blocks, C, CoP, grad_bias);
     UNET_LAUNCH_CHECK("column_sum_kernel");
   }
