@@ -103,6 +103,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=16, help="images per GPU per step")
     ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--base", type=int, default=64, help="channels of the first stage (unet4 graph)")
     ap.add_argument("--graph", default=os.environ.get("UNET_BENCH_GRAPH", "unet4_base64"),
                     choices=["unet4_base64", "mainpy"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -128,8 +129,9 @@ def main():
         dist.init_process_group("nccl", device_id=device)
 
     H = W = args.size
-    graph = (torch_ref.unet_graph(H, W, 3, 64, 4, True) if args.graph == "unet4_base64"
+    graph = (torch_ref.unet_graph(H, W, 3, args.base, 4, True) if args.graph == "unet4_base64"
              else torch_ref.main_py_graph(H, W, 3, 64))
+    free0, _ = torch.cuda.mem_get_info(device)
     net = nn.NeuralNet()
     net.set_seed(1)
     net.create(torch_ref.to_layer_descs(nn, graph), nn.LossFunction.DICE_LOSS)
@@ -140,6 +142,7 @@ def main():
     rng = np.random.default_rng(1234 + rank)
     images = torch.from_numpy(rng.standard_normal((args.batch, 3, H, W)).astype(np.float32)).to(device)
     masks = torch.from_numpy((rng.random((args.batch, H, W)) < 0.03).astype(np.float32)).to(device)
+    free1, _ = torch.cuda.mem_get_info(device)   # engine buffers + the synthetic batch
     trainer = dp.DataParallel(net, device)
     trainer.broadcast_parameters()
     lr = 1e-3
@@ -233,10 +236,11 @@ def main():
         "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
-        "config": {"workload": f"{args.graph} train step (fwd+bwd+Adam, BatchNorm, Dice loss), "
+        "config": {"workload": f"{args.graph if args.base == 64 else 'unet4_base%d' % args.base} train step (fwd+bwd+Adam, BatchNorm, Dice loss), "
                                f"batch {args.batch}x3x{H}x{W} per GPU",
                    "global_batch": args.batch * world, "parallelism": f"dp{world}",
                    "parameters": int(net.num_parameters()), "conv_tflop_per_step": round(step_flops / 1e12, 3)},
+        "hbm_in_use_gb": round((free0 - free1) / 1e9, 2),
         "step_tflops": round(step_flops * world / elapsed * args.steps / 1e12, 2),
         "final_loss": loss,
     }
@@ -261,7 +265,8 @@ def main():
         # (two passes of this same command, summarised by tools/summarize_pmc.py) -- only valid for
         # the default workload the counters were collected on.
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic_per_kernel.json")
-        default_workload = args.graph == "unet4_base64" and args.batch == 16 and args.size == 256 and dtype == "bf16"
+        default_workload = (args.graph == "unet4_base64" and args.batch == 16 and args.size == 256 and
+                            args.base == 64 and dtype == "bf16")
         if default_workload and os.path.exists(tpath):
             want = name.replace(",", ", ")
             for kname, rec in json.load(open(tpath)).items():
