@@ -170,8 +170,14 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float *__restrict
     inv = 1.0f / sqrtf(var + BN_EPS);
   }
   float acc[2] = {0.f, 0.f};
-  for (i64 j = j0 + threadIdx.x; j < j1; j += blockDim.x) {
-    const i64 n = j / HW, i = j - n * HW;
+  // (n, i) of element j advance with j: one 64-bit division per thread, not per element
+  i64 j = j0 + threadIdx.x;
+  i64 n = j / HW, i = j - n * HW;
+  for (; j < j1; j += blockDim.x, i += blockDim.x) {
+    while (i >= HW) {
+      i -= HW;
+      ++n;
+    }
     const i64 idx = (n * C + c) * HW + i;
     const float v = x[idx];
     if (MODE == 0) {
@@ -261,8 +267,12 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float *__restrict__
   }
 }
 
-inline int bn_splits(i64 M) {
+// Slices of the (n, i) range per channel: about 16 K elements each, more when few channels
+// would otherwise leave most of the chip idle (slices stay above 1 K elements).
+inline int bn_splits(i64 M, int C) {
   i64 s = (M + 16383) / 16384;
+  const i64 want = (1024 + C - 1) / C, cap = (M + 1023) / 1024;
+  if (s < want) s = want < cap ? want : cap;
   if (s < 1) s = 1;
   if (s > 512) s = 512;
   return (int)s;
@@ -360,13 +370,16 @@ __global__ __launch_bounds__(256) void chan_copy_kernel(const float *__restrict_
 }
 
 // ---- dice ------------------------------------------------------------------------
+// Sample n, slice blockIdx.y of its pixels -> out[(n*S + slice)*3 + {0,1,2}] (S = gridDim.y; with
+// S == 1 `out` is the loss_values array itself).
 __global__ __launch_bounds__(1024) void dice_sums_kernel(const float *__restrict__ mask,
                                                          const float *__restrict__ pred,
-                                                         float *__restrict__ lv, i64 HW) {
+                                                         float *__restrict__ out, i64 HW) {
   __shared__ float red[3 * 16];
-  const int n = blockIdx.x;
+  const int n = blockIdx.x, S = gridDim.y;
+  const i64 chunk = (HW + S - 1) / S, i0 = (i64)blockIdx.y * chunk, i1 = (i0 + chunk < HW) ? i0 + chunk : HW;
   float acc[3] = {0.f, 0.f, 0.f};
-  for (i64 i = threadIdx.x; i < HW; i += blockDim.x) {
+  for (i64 i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
     const float m = mask[n * HW + i], p = pred[n * HW + i];
     acc[0] += m * p;
     acc[1] += m;
@@ -374,10 +387,20 @@ __global__ __launch_bounds__(1024) void dice_sums_kernel(const float *__restrict
   }
   block_sum<3>(acc, red);
   if (threadIdx.x == 0) {
-    lv[3 * n] = acc[0];
-    lv[3 * n + 1] = acc[1];
-    lv[3 * n + 2] = acc[2];
+    float *o = out + ((i64)n * S + blockIdx.y) * 3;
+    o[0] = acc[0];
+    o[1] = acc[1];
+    o[2] = acc[2];
   }
+}
+// lv[3n + k] = sum over slices, in slice order
+__global__ void dice_sums_finish_kernel(const float *__restrict__ part, float *__restrict__ lv, int N, int S) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= 3 * N) return;
+  const int n = t / 3, k = t - 3 * n;
+  float a = 0.f;
+  for (int s = 0; s < S; ++s) a += part[((i64)n * S + s) * 3 + k];
+  lv[t] = a;
 }
 
 __global__ __launch_bounds__(256) void dice_bwd_kernel(const float *__restrict__ mask,
@@ -528,7 +551,7 @@ int unet_batch_norm_train_f32(const float *inputs, float *activations, const flo
   if (rc) return rc;
   UNET_REQUIRE(inputs && activations && weights && BN_batch_stats, "unet_batch_norm_train_f32: NULL pointer");
   const i64 HW = (i64)H * W, M = HW * N;
-  const int S = bn_splits(M);
+  const int S = bn_splits(M, C);
   void *ws;
   rc = unet_workspace(&ws, sizeof(float) * 2 * (size_t)C * S);
   if (rc) return rc;
@@ -566,7 +589,7 @@ int unet_batch_norm_backward_f32(const float *grad_activations, const float *inp
   UNET_REQUIRE(grad_activations && inputs && BN_batch_stats && weights && grad_inputs && grad_weights,
                "unet_batch_norm_backward_f32: NULL pointer");
   const i64 HW = (i64)H * W, M = HW * N;
-  const int S = bn_splits(M);
+  const int S = bn_splits(M, C);
   void *ws;
   rc = unet_workspace(&ws, sizeof(float) * 2 * (size_t)C * S);
   if (rc) return rc;
@@ -667,9 +690,23 @@ int unet_dice_sums_f32(const float *mask, const float *prediction, int H, int W,
                        float *loss_values, unet_stream_t s) {
   UNET_REQUIRE(N > 0 && H > 0 && W > 0, "dice: need positive sizes");
   UNET_REQUIRE(mask && prediction && loss_values, "dice: NULL pointer");
-  hipLaunchKernelGGL(dice_sums_kernel, dim3(N), dim3(1024), 0, as_stream(s), mask, prediction, loss_values,
-                     (i64)H * W);
+  const i64 HW = (i64)H * W;
+  int S = (int)((256 + N - 1) / N);                       // about one workgroup per CU in total
+  const i64 cap = (HW + 4095) / 4096;                     // at least 4 K pixels per slice
+  if (S > cap) S = (int)cap;
+  if (S <= 1) {
+    hipLaunchKernelGGL(dice_sums_kernel, dim3(N, 1), dim3(1024), 0, as_stream(s), mask, prediction, loss_values, HW);
+    UNET_LAUNCH_CHECK("dice_sums_kernel");
+    return UNET_OK;
+  }
+  void *ws;
+  int rc = unet_workspace(&ws, sizeof(float) * 3 * (size_t)N * S);
+  if (rc) return rc;
+  hipLaunchKernelGGL(dice_sums_kernel, dim3(N, S), dim3(1024), 0, as_stream(s), mask, prediction, (float *)ws, HW);
   UNET_LAUNCH_CHECK("dice_sums_kernel");
+  hipLaunchKernelGGL(dice_sums_finish_kernel, dim3(cdiv_u(3 * N, 64)), dim3(64), 0, as_stream(s), (const float *)ws,
+                     loss_values, N, S);
+  UNET_LAUNCH_CHECK("dice_sums_finish_kernel");
   return UNET_OK;
 }
 int unet_dice_score_f32(const float *mask, const float *prediction, int H, int W, int N,
