@@ -268,12 +268,14 @@ def main():
         default_workload = (args.graph == "unet4_base64" and args.batch == 16 and args.size == 256 and
                             args.base == 64 and dtype == "bf16")
         if default_workload and os.path.exists(tpath):
-            want = name.replace(",", ", ")
-            for kname, rec in json.load(open(tpath)).items():
-                if want in kname:
-                    out["roofline"]["traffic"] = rec["traffic_bytes_per_launch"]
-                    out["roofline"]["algorithmic_bytes_per_launch"] = round(f["bytes"] / f["launches"])
-                    break
+            # "conv_mfma_kernel<9,64>" covers the template instances "conv_mfma_kernel<9, 64, false|true>"
+            # (without / with the fused batch-norm-backward reduction): launch-weighted mean
+            want = name.replace(",", ", ")[:-1]
+            recs = [rec for kname, rec in json.load(open(tpath)).items() if want + ">" in kname or want + "," in kname]
+            if recs:
+                n = sum(r["launches"] for r in recs)
+                out["roofline"]["traffic"] = round(sum(r["traffic_bytes_per_launch"] * r["launches"] for r in recs) / n)
+                out["roofline"]["algorithmic_bytes_per_launch"] = round(f["bytes"] / f["launches"])
         # per-family table from the untimed probe pass (all families timed)
         out["kernel_families"] = {
             k: {"launches_per_step": v["launches"] // probe_steps, "ms_per_step": round(v["ms"] / probe_steps, 3),
