@@ -33,10 +33,10 @@ int unet_set_error(int code, const char *fmt, ...);
                             hipGetErrorString(e_));                                 \
   } while (0)
 
-// Grow-only per-device scratch used by reductions that need partial results.
-// Returned memory is valid until the next unet_workspace() call on the same
-// device that asks for more bytes; all users enqueue on one stream at a time.
-int unet_workspace(void **ptr, size_t bytes);
+// Grow-only scratch used by reductions that need partial results: one block per (device, stream),
+// so launchers working on different streams never share it.  The returned memory is valid until
+// the next unet_workspace() call for the same device and stream that asks for more bytes.
+int unet_workspace(void **ptr, size_t bytes, hipStream_t stream);
 void unet_workspace_release_all();
 
 static inline hipStream_t as_stream(unet_stream_t s) { return (hipStream_t)s; }

@@ -457,7 +457,7 @@ int unet_convolve_backward_f32(const float *grad_activations, const float *input
   const int splits = pick_splits((i64)Ci * cogroups, rows, Wo);
   const int rps = (rows + splits - 1) / splits;
   void *ws;
-  int rc = unet_workspace(&ws, sizeof(float) * (size_t)splits * (size_t)(nW + Co));
+  int rc = unet_workspace(&ws, sizeof(float) * (size_t)splits * (size_t)(nW + Co), as_stream(s));
   if (rc) return rc;
   dim3 grid((unsigned)splits, (unsigned)cogroups, (unsigned)Ci);
   ProfScope prof(PROF_CONV_WGRAD_F32, 2.0 * N * Co * Ho * Wo * (double)Ci * k * k,
@@ -515,7 +515,7 @@ int unet_upsample_backward_f32(const float *grad_activations, const float *input
   const int splits = pick_splits((i64)Ci * cogroups, rows, Wi);
   const int rps = (rows + splits - 1) / splits;
   void *ws;
-  int rc = unet_workspace(&ws, sizeof(float) * (size_t)splits * (size_t)(nW + Co));
+  int rc = unet_workspace(&ws, sizeof(float) * (size_t)splits * (size_t)(nW + Co), as_stream(s));
   if (rc) return rc;
   dim3 grid((unsigned)splits, (unsigned)cogroups, (unsigned)Ci);
 #define LAUNCH_UW(S_, COB_)                                                                                   \

@@ -536,7 +536,7 @@ int unet_bn_act_backward_bf16(const uint16_t *dy1, int ld1, const uint16_t *dy2,
   // workspace: partials [blocks][CoP][2] | ChanBwd [CoP] | bias partials [blocks][CoP]
   const size_t n_part = (size_t)pl.blocks * CoP * 2, n_cb = (size_t)CoP * 4, n_bias = (size_t)pl.blocks * CoP;
   void *ws;
-  rc = unet_workspace(&ws, sizeof(float) * (n_part + n_cb + n_bias));
+  rc = unet_workspace(&ws, sizeof(float) * (n_part + n_cb + n_bias), as_stream(s));
   if (rc) return rc;
   float *partial = (float *)ws, *cbf = partial + n_part, *bias_part = cbf + n_cb;
   const ChanFwd *cf = reinterpret_cast<const ChanFwd *>(coef);
@@ -590,7 +590,7 @@ int unet_bn_act_backward_from_partials_bf16(const uint16_t *dy, int dy_ld, const
   // workspace: ChanBwd [CoP] | bias partials [blocks][CoP]
   const size_t n_cb = (size_t)CoP * 4, n_bias = (size_t)pl.blocks * CoP;
   void *ws;
-  rc = unet_workspace(&ws, sizeof(float) * (n_cb + n_bias));
+  rc = unet_workspace(&ws, sizeof(float) * (n_cb + n_bias), as_stream(s));
   if (rc) return rc;
   float *cbf = (float *)ws, *bias_part = cbf + n_cb;
   const ChanFwd *cf = reinterpret_cast<const ChanFwd *>(coef);

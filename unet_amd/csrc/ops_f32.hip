@@ -521,7 +521,7 @@ int unet_has_nans_f32(const float *ptr, int64_t n, int *has_nan_host, unet_strea
   *has_nan_host = 0;
   if (!ptr || n <= 0) return UNET_OK;
   void *ws;
-  int rc = unet_workspace(&ws, 256);
+  int rc = unet_workspace(&ws, 256, as_stream(s));
   if (rc) return rc;
   UNET_HIP_TRY(hipMemsetAsync(ws, 0, 4, as_stream(s)));
   hipLaunchKernelGGL(has_nan_kernel, dim3(ew_grid(n)), dim3(256), 0, as_stream(s), ptr, (i64)n, (int *)ws);
@@ -553,7 +553,7 @@ int unet_batch_norm_train_f32(const float *inputs, float *activations, const flo
   const i64 HW = (i64)H * W, M = HW * N;
   const int S = bn_splits(M, C);
   void *ws;
-  rc = unet_workspace(&ws, sizeof(float) * 2 * (size_t)C * S);
+  rc = unet_workspace(&ws, sizeof(float) * 2 * (size_t)C * S, as_stream(s));
   if (rc) return rc;
   hipLaunchKernelGGL(bn_partial_kernel<0>, dim3(S, C), dim3(256), 0, as_stream(s), inputs,
                      (const float *)nullptr, (const float *)nullptr, (float *)ws, C, HW, M, S);
@@ -591,7 +591,7 @@ int unet_batch_norm_backward_f32(const float *grad_activations, const float *inp
   const i64 HW = (i64)H * W, M = HW * N;
   const int S = bn_splits(M, C);
   void *ws;
-  rc = unet_workspace(&ws, sizeof(float) * 2 * (size_t)C * S);
+  rc = unet_workspace(&ws, sizeof(float) * 2 * (size_t)C * S, as_stream(s));
   if (rc) return rc;
   hipLaunchKernelGGL(bn_partial_kernel<1>, dim3(S, C), dim3(256), 0, as_stream(s), inputs, grad_activations,
                      BN_batch_stats, (float *)ws, C, HW, M, S);
@@ -700,7 +700,7 @@ int unet_dice_sums_f32(const float *mask, const float *prediction, int H, int W,
     return UNET_OK;
   }
   void *ws;
-  int rc = unet_workspace(&ws, sizeof(float) * 3 * (size_t)N * S);
+  int rc = unet_workspace(&ws, sizeof(float) * 3 * (size_t)N * S, as_stream(s));
   if (rc) return rc;
   hipLaunchKernelGGL(dice_sums_kernel, dim3(N, S), dim3(1024), 0, as_stream(s), mask, prediction, (float *)ws, HW);
   UNET_LAUNCH_CHECK("dice_sums_kernel");
@@ -748,7 +748,7 @@ int unet_softmax_xent_f32(const float *logits, const int32_t *target, float *dlo
   unsigned nb = ew_grid(P);
   if (nb > 1024) nb = 1024;
   void *ws;
-  int rc = unet_workspace(&ws, sizeof(float) * nb);
+  int rc = unet_workspace(&ws, sizeof(float) * nb, as_stream(s));
   if (rc) return rc;
   const float inv_p = 1.0f / (float)P;
   hipLaunchKernelGGL(xent_kernel, dim3(nb), dim3(256), 0, as_stream(s), logits, target, dlogits, (float *)ws, C,

@@ -20,33 +20,41 @@ int unet_set_error(int code, const char *fmt, ...) {
 // ---- workspace -------------------------------------------------------------
 namespace {
 struct Workspace {
+  int dev = -1;
+  hipStream_t stream = nullptr;
   void *ptr = nullptr;
   size_t bytes = 0;
 };
-constexpr int kMaxDevices = 64;
-Workspace g_ws[kMaxDevices];
+std::vector<Workspace> g_ws;  // one block per (device, stream) that ever asked
 std::mutex g_ws_mu;
 }  // namespace
 
-int unet_workspace(void **ptr, size_t bytes) {
+int unet_workspace(void **ptr, size_t bytes, hipStream_t stream) {
   int dev = 0;
   UNET_HIP_TRY(hipGetDevice(&dev));
-  UNET_REQUIRE(dev >= 0 && dev < kMaxDevices, "device index %d out of range", dev);
   std::lock_guard<std::mutex> lk(g_ws_mu);
-  Workspace &w = g_ws[dev];
-  if (w.bytes < bytes) {
+  Workspace *w = nullptr;
+  for (Workspace &e : g_ws)
+    if (e.dev == dev && e.stream == stream) w = &e;
+  if (!w) {
+    g_ws.push_back(Workspace());
+    w = &g_ws.back();
+    w->dev = dev;
+    w->stream = stream;
+  }
+  if (w->bytes < bytes) {
     // Kernels still reading the old block must finish before it is freed.
-    if (w.ptr) {
+    if (w->ptr) {
       UNET_HIP_TRY(hipDeviceSynchronize());
-      UNET_HIP_TRY(hipFree(w.ptr));
-      w.ptr = nullptr;
-      w.bytes = 0;
+      UNET_HIP_TRY(hipFree(w->ptr));
+      w->ptr = nullptr;
+      w->bytes = 0;
     }
     size_t want = bytes < (size_t)(8u << 20) ? (size_t)(8u << 20) : bytes + bytes / 2;
-    UNET_HIP_TRY(hipMalloc(&w.ptr, want));
-    w.bytes = want;
+    UNET_HIP_TRY(hipMalloc(&w->ptr, want));
+    w->bytes = want;
   }
-  *ptr = w.ptr;
+  *ptr = w->ptr;
   return UNET_OK;
 }
 
@@ -54,12 +62,12 @@ void unet_workspace_release_all() {
   std::lock_guard<std::mutex> lk(g_ws_mu);
   int cur = 0;
   if (hipGetDevice(&cur) != hipSuccess) return;
-  for (int d = 0; d < kMaxDevices; ++d)
-    if (g_ws[d].ptr) {
-      (void)hipSetDevice(d);
-      (void)hipFree(g_ws[d].ptr);
-      g_ws[d] = Workspace();
+  for (Workspace &e : g_ws)
+    if (e.ptr) {
+      (void)hipSetDevice(e.dev);
+      (void)hipFree(e.ptr);
     }
+  g_ws.clear();
   (void)hipSetDevice(cur);
 }
 

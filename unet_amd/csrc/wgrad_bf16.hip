@@ -258,7 +258,7 @@ static int run_wgrad(int taps, int phases, const WgradArgs &base, float *grad, i
   a.chunks_per_split = (a.total_chunks + splits - 1) / splits;
   splits = (a.total_chunks + a.chunks_per_split - 1) / a.chunks_per_split;
   void *ws;
-  int rc = unet_workspace(&ws, sizeof(float) * (size_t)splits * slices * a.CoP * a.CiP);
+  int rc = unet_workspace(&ws, sizeof(float) * (size_t)splits * slices * a.CoP * a.CiP, s);
   if (rc) return rc;
   a.partial = (float *)ws;
   const size_t lds = (size_t)128 * WP + (size_t)(taps == 9 ? 180 : 128) * WP;
