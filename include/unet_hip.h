@@ -300,11 +300,15 @@ int unet_conv3x3_stat_tiles(int H, int W);
  * written (not accumulated), and red_partials receives [N][tiles][CoP][2]
  * per-tile (sum g*xhat, sum g) with g = dx * relu'(a*z+b), where bn_z is that
  * layer's pre-BN tensor and bn_coef its unet_bn_finalize_bf16 records; feed
- * them to unet_bn_act_backward_from_partials_bf16. */
+ * them to unet_bn_act_backward_from_partials_bf16.  When the input is a concat
+ * and only its second half comes from such a layer, bn_first_channel is the
+ * first channel of that half (a multiple of 64): bn_z, bn_coef and the
+ * partials then cover channels [bn_first_channel, CoP) renumbered from 0, and
+ * the partial rows are CoP - bn_first_channel channels wide. */
 int unet_conv3x3_dgrad_bnred_bf16(const uint16_t *dz, int dz_ld, const uint16_t *w_packed_bwd, uint16_t *dx,
                                   int dx_ld, const uint16_t *bn_z, int bn_z_ld, const float *bn_coef,
-                                  float *red_partials, int N, int H, int W, int CiP, int CoP,
-                                  unet_stream_t stream);
+                                  float *red_partials, int bn_first_channel, int N, int H, int W, int CiP,
+                                  int CoP, unet_stream_t stream);
 /* Weight-gradient half of cudaConvolveBackward: grad_w [Ci][Co][3][3] fp32
  * (overwritten) = sum over pixels of dz x shifted x.  Deterministic. */
 int unet_conv3x3_wgrad_bf16(const uint16_t *dz, int dz_ld, const uint16_t *x, int x_ld, float *grad_w, int N, int H,

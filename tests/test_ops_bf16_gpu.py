@@ -319,7 +319,7 @@ def test_dgrad_with_fused_bn_backward_reduction(G, capi, cfg):
         if fused:
             parts = G.empty((n * tiles * cp * 2,))
             if kind == "conv":
-                capi.unet_conv3x3_dgrad_bnred_bf16(G.p(dzn), cn, G.p(wb), G.p(dx), cp, G.p(zp), cp, G.p(coef), G.p(parts),
+                capi.unet_conv3x3_dgrad_bnred_bf16(G.p(dzn), cn, G.p(wb), G.p(dx), cp, G.p(zp), cp, G.p(coef), G.p(parts), 0,
                                                    n, h, w, cn, cp, None)
             else:
                 capi.unet_tconv2x2_dgrad_bnred_bf16(G.p(dzn), cn, G.p(wb), G.p(dx), cp, G.p(zp), cp, G.p(coef),
@@ -344,3 +344,42 @@ def test_dgrad_with_fused_bn_backward_reduction(G, capi, cfg):
     assert_close(gbias_b, gbias_a, rtol=1e-3, atol_scale=1e-4, what="dbias")
     # dz is bf16: the two paths may differ by one rounding where the fp32 value sits on a boundary
     assert_close_bf16(dz_b, dz_a, what="dz")
+
+
+def test_dgrad_fused_reduction_on_second_half_of_a_concat(G, capi):
+    """bn_first_channel = 64 of 128 output channels: the first half of dx is a plain data gradient,
+    the second half also yields the BN-backward partial sums of the layer that produced it."""
+    n, cn, h, w, c1, c2 = 2, 64, 24, 16, 64, 64
+    cp = c1 + c2
+    rng = np.random.default_rng(12)
+    dzn = torch.from_numpy(rng.standard_normal((n, h, w, cn)).astype(np.float32)).to(G.DEV).bfloat16()
+    wflat = (rng.standard_normal(cp * cn * 9 + cn) * 0.1).astype(np.float32)
+    _, wb = pack(G, capi, wflat, cp, cn, 3)
+    zu = torch.from_numpy(rng.standard_normal((n, h, w, c2)).astype(np.float32)).to(G.DEV).bfloat16()
+    gb = G.dev((rng.random(2 * c2) + 0.5).astype(np.float32))
+    coef = G.dev(np.stack([rng.random(c2) + 0.5, rng.standard_normal(c2) * 0.3, rng.standard_normal(c2) * 0.1,
+                           rng.random(c2) + 0.7], axis=1).astype(np.float32).reshape(-1))
+    pixels, tiles = n * h * w, capi.lib().unet_conv3x3_stat_tiles(h, w)
+    dx_a = torch.zeros((n, h, w, cp), dtype=torch.bfloat16, device=G.DEV)
+    dx_b = torch.zeros_like(dx_a)
+    capi.unet_conv3x3_bf16(G.p(dzn), cn, G.p(wb), None, 0, G.p(dx_a), cp, None, n, h, w, cn, cp, 0, None)
+    parts = G.empty((n * tiles * c2 * 2,))
+    capi.unet_conv3x3_dgrad_bnred_bf16(G.p(dzn), cn, G.p(wb), G.p(dx_b), cp, G.p(zu), c2, G.p(coef), G.p(parts), c1,
+                                       n, h, w, cn, cp, None)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(dx_a.float().cpu().numpy(), dx_b.float().cpu().numpy())
+    out = {}
+    for name, fused in (("sep", False), ("fused", True)):
+        dzu = torch.zeros((n, h, w, c2), dtype=torch.bfloat16, device=G.DEV)
+        ggb, gbias = G.empty((2 * c2,)), G.empty((c2,))
+        dy_slice = dx_a.data_ptr() + 2 * c1         # channels [c1, c1+c2) of the concat gradient, pixel stride cp
+        if fused:
+            capi.unet_bn_act_backward_from_partials_bf16(dy_slice, cp, G.p(zu), c2, G.p(coef), G.p(gb), G.p(parts),
+                                                         n * tiles, G.p(dzu), c2, G.p(ggb), G.p(gbias), c2, c2, pixels, None)
+        else:
+            capi.unet_bn_act_backward_bf16(dy_slice, cp, None, 0, G.p(zu), c2, G.p(coef), G.p(gb), G.p(dzu), c2, G.p(ggb),
+                                           G.p(gbias), c2, c2, pixels, 0, None)
+        torch.cuda.synchronize()
+        out[name] = (dzu.float().cpu().numpy(), G.host(ggb), G.host(gbias))
+    assert_close(out["fused"][1], out["sep"][1], rtol=1e-4, atol_scale=1e-5, what="dgamma/dbeta")
+    assert_close_bf16(out["fused"][0], out["sep"][0], what="dz")

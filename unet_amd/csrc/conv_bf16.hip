@@ -57,6 +57,8 @@ struct ConvArgs {
   const bf16_t *bz;
   int bz_ld;
   const float4 *bcf;
+  int bred_c0;  // output channels below this one take no part (the other half of a concat's gradient);
+                // bz, bcf and stats are indexed by (channel - bred_c0), stats rows hold CoP - bred_c0 channels
 };
 
 constexpr int PITCH = 80;  // bytes per LDS row of 32 bf16 (64 B payload + 16 B pad)
@@ -208,9 +210,11 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
   constexpr int CHB = BN / 8;
   uint4 zq[BRED ? CHB : 1];
   float4 bcf[BRED ? 8 : 1];  // BN records of the 8 channels this thread handles in the store pass
-  if (BRED) {
+  const bool red_here = BRED && co0 >= a.bred_c0;  // uniform over the workgroup
+  const int rc0 = co0 - a.bred_c0;                 // first channel of this block in the BN layer's numbering
+  if (red_here) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) bcf[j] = a.bcf[co0 + (tid % CHB) * 8 + j];
+    for (int j = 0; j < 8; ++j) bcf[j] = a.bcf[rc0 + (tid % CHB) * 8 + j];
 #pragma unroll
     for (int i = 0; i < CHB; ++i) {
       const int pix = tid / CHB + i * (256 / CHB);
@@ -219,7 +223,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
       if (y < a.Ho && x < a.Wo)
         zq[i] = *reinterpret_cast<const uint4 *>(
             a.bz + (n * (i64)a.Hout * a.Wout + (i64)(y * a.out_s + out_oy) * a.Wout + (x * a.out_s + out_ox)) * a.bz_ld +
-            co0 + (tid % CHB) * 8);
+            rc0 + (tid % CHB) * 8);
     }
   }
 #pragma unroll
@@ -252,7 +256,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
     const int y = y0 + (pix >> 4), x = x0 + (pix & 15);
     if (y < a.Ho && x < a.Wo) {
       uint4 v = *reinterpret_cast<const uint4 *>(stage + pix * OP + part * 16);
-      if (BRED) {
+      if (BRED && red_here) {
         const uint32_t vv[4] = {v.x, v.y, v.z, v.w}, zz[4] = {zq[i].x, zq[i].y, zq[i].z, zq[i].w};
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -288,11 +292,11 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
       *reinterpret_cast<uint4 *>(dst) = v;
     }
   }
-  if (BRED) {  // sum g*xhat = (sum g*z - mean * sum g) / sqrt(var + eps)
+  if (BRED && red_here) {  // sum g*xhat = (sum g*z - mean * sum g) / sqrt(var + eps)
 #pragma unroll
     for (int j = 0; j < 8; ++j) ssum[j] = (ssum[j] - bcf[j].z * ssq[j]) * bcf[j].w;
   }
-  if (BRED || stats) {
+  if (BRED ? red_here : (stats != nullptr)) {
     // lanes with equal (lane % CH) hold the same 8 channels: butterfly over the other lane bits,
     // then one partial per wave through LDS, summed in wave order (deterministic)
 #pragma unroll
@@ -313,7 +317,10 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
     __syncthreads();
     if (tid < 2 * BN) {
       const float t = (red[tid] + red[2 * BN + tid]) + (red[4 * BN + tid] + red[6 * BN + tid]);
-      stats[((n * gridDim.x + tile) * (i64)a.CoP + co0) * 2 + tid] = t;
+      if (BRED)
+        stats[((n * gridDim.x + tile) * (i64)(a.CoP - a.bred_c0) + rc0) * 2 + tid] = t;
+      else
+        stats[((n * gridDim.x + tile) * (i64)a.CoP + co0) * 2 + tid] = t;
     }
   }
 }
@@ -524,12 +531,17 @@ int unet_conv3x3_stat_tiles(int H, int W) { return ((H + 15) / 16) * ((W + 15) /
 
 int unet_conv3x3_dgrad_bnred_bf16(const uint16_t *dz, int dz_ld, const uint16_t *w_packed_bwd, uint16_t *dx,
                                   int dx_ld, const uint16_t *bn_z, int bn_z_ld, const float *bn_coef,
-                                  float *red_partials, int N, int H, int W, int CiP, int CoP, unet_stream_t s) {
+                                  float *red_partials, int bn_first_channel, int N, int H, int W, int CiP, int CoP,
+                                  unet_stream_t s) {
   UNET_REQUIRE(dz && w_packed_bwd && dx && bn_z && bn_coef && red_partials, "unet_conv3x3_dgrad_bnred_bf16: NULL pointer");
   UNET_REQUIRE(N > 0 && N <= 65535 && H > 0 && W > 0, "unet_conv3x3_dgrad_bnred_bf16: bad sizes");
   UNET_REQUIRE(CiP > 0 && CiP % 32 == 0 && CoP > 0 && CoP % 32 == 0 && dz_ld >= CiP && dx_ld >= CoP &&
-                   bn_z_ld >= CoP && dz_ld % 8 == 0 && dx_ld % 8 == 0 && bn_z_ld % 8 == 0,
+                   dz_ld % 8 == 0 && dx_ld % 8 == 0 && bn_z_ld % 8 == 0,
                "unet_conv3x3_dgrad_bnred_bf16: channel counts must be multiples of 32 and pixel strides multiples of 8");
+  UNET_REQUIRE(bn_first_channel >= 0 && bn_first_channel < CoP && bn_first_channel % (CoP % 64 == 0 ? 64 : 32) == 0 &&
+                   bn_z_ld >= CoP - bn_first_channel,
+               "unet_conv3x3_dgrad_bnred_bf16: bn_first_channel must be a multiple of the 64-channel block (32 when "
+               "CoP is not a multiple of 64) and bn_z must hold CoP - bn_first_channel channels");
   UNET_REQUIRE((((uintptr_t)dz | (uintptr_t)dx | (uintptr_t)w_packed_bwd | (uintptr_t)bn_z | (uintptr_t)bn_coef) & 15) == 0,
                "unet_conv3x3_dgrad_bnred_bf16: pointers must be 16-byte aligned");
   UNET_REQUIRE((i64)H * W * dz_ld < (1ll << 31) && (i64)H * W * dx_ld < (1ll << 31) && (i64)H * W * bn_z_ld < (1ll << 31),
@@ -541,6 +553,7 @@ int unet_conv3x3_dgrad_bnred_bf16(const uint16_t *dz, int dz_ld, const uint16_t 
   a.tilesX = (W + 15) / 16;
   a.out_phases = a.k_phases = 1;
   a.bz = bn_z; a.bz_ld = bn_z_ld; a.bcf = reinterpret_cast<const float4 *>(bn_coef);
+  a.bred_c0 = bn_first_channel;
   ProfScope prof(PROF_CONV_DGRAD_BF16, 2.0 * N * H * W * (double)CiP * CoP * 9,
                  2.0 * N * H * W * ((double)CiP + 2.0 * CoP), as_stream(s));
   return launch_conv_any(9, a, as_stream(s));

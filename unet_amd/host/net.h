@@ -947,6 +947,14 @@ class Net {
     }
   }
 
+  // concat node c: its second parent is a BN + ReLU layer whose only consumer is c, and the channel
+  // split sits on a 64-channel block boundary of the data-gradient kernel
+  bool concat_second_is_fusable(const Node &c) const {
+    const Node &u = nodes_[c.parents[1]];
+    return u.has_params() && !u.narrow && u.num_children == 1 && c.num_children == 1 && c.c1 % 64 == 0 &&
+           c.cop % 64 == 0 && u.cop == c.c2 && !(u.type == CONV_LAYER && u.activation == SIGMOID);
+  }
+
   void backward_node_bf16(Node &n, int batch) {
     const int64_t out_pix = (int64_t)batch * n.out_h * n.out_w;
     switch (n.type) {
@@ -998,13 +1006,21 @@ class Net {
           if (fuse) {
             if (n.type == CONV_LAYER)
               UNET_CALL(unet_conv3x3_dgrad_bnred_bf16(dz, n.cop, n.w_bwd.u16(), p.gb.u16(), p.cop, p.zb.u16(), p.cop,
-                                                      p.coef.f32(), p.bwd_partials.f32(), batch, n.in_h, n.in_w, n.cop,
-                                                      n.cip, stream_));
+                                                      p.coef.f32(), p.bwd_partials.f32(), 0, batch, n.in_h, n.in_w,
+                                                      n.cop, n.cip, stream_));
             else
               UNET_CALL(unet_tconv2x2_dgrad_bnred_bf16(dz, n.cop, n.w_bwd.u16(), p.gb.u16(), p.cop, p.zb.u16(), p.cop,
                                                        p.coef.f32(), p.bwd_partials.f32(), batch, n.in_h, n.in_w, n.cip,
                                                        n.cop, stream_));
             p.bwd_partials_n = batch * unet_conv3x3_stat_tiles(n.in_h, n.in_w);
+          } else if (n.type == CONV_LAYER && p.type == CONCAT_LAYER && !p.g_written && concat_second_is_fusable(p)) {
+            // Input = concat(skip, up): the second half of the gradient is all the gradient the
+            // upsampling layer's BN + ReLU output receives, so its pixel reduction is fused here too.
+            Node &u = nodes_[p.parents[1]];
+            UNET_CALL(unet_conv3x3_dgrad_bnred_bf16(dz, n.cop, n.w_bwd.u16(), p.gb.u16(), p.cop, u.zb.u16(), u.cop,
+                                                    u.coef.f32(), u.bwd_partials.f32(), p.c1, batch, n.in_h, n.in_w,
+                                                    n.cop, n.cip, stream_));
+            u.bwd_partials_n = batch * unet_conv3x3_stat_tiles(n.in_h, n.in_w);
           } else if (n.type == CONV_LAYER) {
             UNET_CALL(unet_conv3x3_bf16(dz, n.cop, n.w_bwd.u16(), nullptr, 0, p.gb.u16(), p.cop, nullptr, batch, n.in_h,
                                         n.in_w, n.cop, n.cip, p.g_written ? 1 : 0, stream_));
