@@ -154,21 +154,11 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
   const int a_lane = (lane & 31) * PITCH + (lane >> 5) * 16;
   const int b_lane = ((wave * 4 + ((lane & 31) >> 4)) * HALO + (lane & 15)) * PITCH + (lane >> 5) * 16;
 
-  // bias of this lane's accumulator channels, fetched now so that its latency hides behind the K loop
-  f32x4 bias_r[MF][4];
-#pragma unroll
-  for (int m = 0; m < MF; ++m)
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int ch = co0 + m * 32 + 8 * g + 4 * (lane >> 5);
-      bias_r[m][g] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (!BRED && a.bias) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if (ch + j < a.co_valid) bias_r[m][g][j] = a.bias[ch + j];
-      }
-    }
-
+  // bias of this workgroup's channels: one global load per thread into LDS (behind the staging buffers),
+  // read back as broadcast 16-byte pieces in the epilogue
+  constexpr int MAIN_BYTES = W_BYTES + NPIX * PITCH, EPI_BYTES = 256 * (BN * 2 + 16) + 2048;
+  float *ldsB = reinterpret_cast<float *>(lds + (MAIN_BYTES > EPI_BYTES ? MAIN_BYTES : EPI_BYTES));
+  if (!BRED && tid < BN) ldsB[tid] = (a.bias && co0 + tid < a.co_valid) ? a.bias[co0 + tid] : 0.f;
 
   const int nk = (TAPS == 1) ? nk1 * a.k_phases : nk1;
   load_chunk(0);
@@ -235,7 +225,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
       for (int g = 0; g < 4; ++g) {
         const int ch = m * 32 + 8 * g + 4 * (lane >> 5);
         f32x4 v = {acc[m][q][4 * g], acc[m][q][4 * g + 1], acc[m][q][4 * g + 2], acc[m][q][4 * g + 3]};
-        if (!BRED) v += bias_r[m][g];
+        if (!BRED) v += *reinterpret_cast<const f32x4 *>(ldsB + ch);
         const bf16x4 h = __builtin_convertvector(v, bf16x4);
         *reinterpret_cast<bf16x4 *>(stage + pix * OP + ch * 2) = h;
       }
@@ -329,8 +319,8 @@ template <int TAPS, int BN>
 constexpr size_t conv_lds_bytes() {
   constexpr int HALO = (TAPS == 9) ? 18 : 16;
   constexpr size_t main_loop = (size_t)TAPS * BN * PITCH + (size_t)HALO * HALO * PITCH;
-  constexpr size_t epilogue = (size_t)256 * (BN * 2 + 16) + 4096;
-  return main_loop > epilogue ? main_loop : epilogue;
+  constexpr size_t epilogue = (size_t)256 * (BN * 2 + 16) + 2048;
+  return (main_loop > epilogue ? main_loop : epilogue) + BN * sizeof(float);  // + the bias vector
 }
 
 template <int TAPS, int BN, bool BRED>

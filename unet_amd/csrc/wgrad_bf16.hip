@@ -250,9 +250,11 @@ static int run_wgrad(int taps, int phases, const WgradArgs &base, float *grad, i
   a.chunksY = (a.H + 7) / 8;
   a.total_chunks = a.N * a.chunksX * a.chunksY;
   const int tiles = (a.CoP / 64) * (a.CiP / 64);
-  // two workgroups per CU's worth of blocks: small enough slices that a CU lent to a concurrent
-  // collective costs little, large enough that the partial sums stay a minor part of the traffic
-  int splits = (512 / phases + tiles - 1) / tiles;
+  // every workgroup writes a 64 x 64 x taps fp32 partial block, so the number of workgroups sets the
+  // partial-sum traffic: one per CU for the 3x3 filters (147 KB each; measured faster in sum with the
+  // reduction than two per CU), two per CU for the 16 KB blocks of the transposed convolution
+  const int target_blocks = taps == 9 ? 256 : 512;
+  int splits = (target_blocks / phases + tiles - 1) / tiles;
   if (splits > a.total_chunks) splits = a.total_chunks;
   if (splits < 1) splits = 1;
   a.chunks_per_split = (a.total_chunks + splits - 1) / splits;
