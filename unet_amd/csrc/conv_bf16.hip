@@ -61,15 +61,18 @@ struct ConvArgs {
                 // bz, bcf and stats are indexed by (channel - bred_c0), stats rows hold CoP - bred_c0 channels
 };
 
-constexpr int PITCH = 80;  // bytes per LDS row of 32 bf16 (64 B payload + 16 B pad)
-
-template <int TAPS, int BN, bool BRED = false>
+// KC = channels staged per main-loop trip: 32 for the 3x3 kernels (the 9-tap weight slab sets the LDS
+// budget); 64 for the 1x1 kernels when the channel count allows, whose trips are otherwise too short to
+// cover a load's latency
+template <int TAPS, int BN, bool BRED, int KC>
 __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
+  constexpr int PITCH = KC * 2 + 16;  // bytes per LDS row of KC bf16; the 16-byte pad spreads rows over the banks
+  constexpr int PPR = KC / 8;         // 16-byte pieces per row
   constexpr int HALO = (TAPS == 9) ? 18 : 16;
   constexpr int NPIX = HALO * HALO;
   constexpr int W_BYTES = TAPS * BN * PITCH;
-  constexpr int XCH = NPIX * 4, XI = (XCH + 255) / 256;       // 16-byte pieces of the halo patch
-  constexpr int WCH = TAPS * BN * 4, WI = (WCH + 255) / 256;  // 16-byte pieces of the weight slice
+  constexpr int XCH = NPIX * PPR, XI = (XCH + 255) / 256;       // 16-byte pieces of the halo patch
+  constexpr int WCH = TAPS * BN * PPR, WI = (WCH + 255) / 256;  // 16-byte pieces of the weight slice
   constexpr int MF = BN / 32;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   unsigned char *ldsW = lds, *ldsX = lds + W_BYTES;
@@ -96,7 +99,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
   int xoff[XI];
 #pragma unroll
   for (int i = 0; i < XI; ++i) {
-    const int c = tid + 256 * i, pix = c >> 2, part = c & 3;
+    const int c = tid + 256 * i, pix = c / PPR, part = c % PPR;
     const int py = pix / HALO, px = pix - py * HALO;
     const int y = y0 + py - (TAPS == 9), x = x0 + px - (TAPS == 9);
     const bool ok = c < XCH && y >= 0 && y < a.Ho && x >= 0 && x < a.Wo;
@@ -105,14 +108,14 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
   }
   const bf16_t *w_thread = wt + (i64)co0 * a.Ci;  // + (tap*CoP + co)*Ci + part*8 + k0
 
-  const int nk1 = a.Ci / 32;  // chunks per reduction phase
+  const int nk1 = a.Ci / KC;  // chunks per reduction phase
   uint4 xr[XI], wr[WI];
   auto load_chunk = [&](int kc) {
-    int k0 = kc * 32;
+    int k0 = kc * KC;
     i64 xo = k0, wo = k0;
     if (TAPS == 1 && a.k_phases > 1) {
       const int ph = kc / nk1;
-      k0 = (kc - ph * nk1) * 32;
+      k0 = (kc - ph * nk1) * KC;
       xo = k0 + (i64)((ph >> 1) * a.Win + (ph & 1)) * a.in_ld;
       wo = k0 + ph * a.wt_phase_stride;
     }
@@ -123,7 +126,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
     }
 #pragma unroll
     for (int i = 0; i < WI; ++i) {
-      const int c = tid + 256 * i, row = c >> 2, part = c & 3;
+      const int c = tid + 256 * i, row = c / PPR, part = c % PPR;
       const int tap = row / BN, co = row % BN;
       wr[i] = make_uint4(0, 0, 0, 0);
       if (WCH % 256 == 0 || c < WCH)
@@ -134,12 +137,12 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
 #pragma unroll
     for (int i = 0; i < XI; ++i) {
       const int c = tid + 256 * i;
-      if (XCH % 256 == 0 || c < XCH) *reinterpret_cast<uint4 *>(ldsX + (c >> 2) * PITCH + (c & 3) * 16) = xr[i];
+      if (XCH % 256 == 0 || c < XCH) *reinterpret_cast<uint4 *>(ldsX + (c / PPR) * PITCH + (c % PPR) * 16) = xr[i];
     }
 #pragma unroll
     for (int i = 0; i < WI; ++i) {
       const int c = tid + 256 * i;
-      if (WCH % 256 == 0 || c < WCH) *reinterpret_cast<uint4 *>(ldsW + (c >> 2) * PITCH + (c & 3) * 16) = wr[i];
+      if (WCH % 256 == 0 || c < WCH) *reinterpret_cast<uint4 *>(ldsW + (c / PPR) * PITCH + (c % PPR) * 16) = wr[i];
     }
   };
 
@@ -170,7 +173,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
     for (int tap = 0; tap < TAPS; ++tap) {
       const int kh = (TAPS == 9) ? tap / 3 : 0, kw = (TAPS == 9) ? tap % 3 : 0;
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
+      for (int ks = 0; ks < KC / 16; ++ks) {
         bf16x8 af[MF], bfr[2];
 #pragma unroll
         for (int m = 0; m < MF; ++m)
@@ -315,41 +318,44 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
   }
 }
 
-template <int TAPS, int BN>
+template <int TAPS, int BN, int KC>
 constexpr size_t conv_lds_bytes() {
   constexpr int HALO = (TAPS == 9) ? 18 : 16;
+  constexpr int PITCH = KC * 2 + 16;
   constexpr size_t main_loop = (size_t)TAPS * BN * PITCH + (size_t)HALO * HALO * PITCH;
   constexpr size_t epilogue = (size_t)256 * (BN * 2 + 16) + 2048;
   return (main_loop > epilogue ? main_loop : epilogue) + BN * sizeof(float);  // + the bias vector
 }
 
-template <int TAPS, int BN, bool BRED>
+template <int TAPS, int BN, bool BRED, int KC = 32>
 int launch_conv(const ConvArgs &a, hipStream_t s) {
   static bool attr_set[64] = {};
-  constexpr size_t lds = conv_lds_bytes<TAPS, BN>();
+  constexpr size_t lds = conv_lds_bytes<TAPS, BN, KC>();
   int dev = 0;
   UNET_HIP_TRY(hipGetDevice(&dev));
   if (!attr_set[dev & 63]) {
-    UNET_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_mfma_kernel<TAPS, BN, BRED>),
+    UNET_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_mfma_kernel<TAPS, BN, BRED, KC>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set[dev & 63] = true;
   }
   const int tilesY = (a.Ho + 15) / 16;
   dim3 grid((unsigned)(tilesY * a.tilesX), (unsigned)(a.CoP / BN * (a.out_phases > 1 ? a.out_phases : 1)),
             (unsigned)a.N);
-  hipLaunchKernelGGL((conv_mfma_kernel<TAPS, BN, BRED>), grid, dim3(256), lds, s, a);
+  hipLaunchKernelGGL((conv_mfma_kernel<TAPS, BN, BRED, KC>), grid, dim3(256), lds, s, a);
   UNET_LAUNCH_CHECK("conv_mfma_kernel");
   return UNET_OK;
 }
 
 int launch_conv_any(int taps, const ConvArgs &a, hipStream_t s) {
-  const bool wide = a.CoP % 64 == 0;
+  const bool wide = a.CoP % 64 == 0, deep = a.Ci % 64 == 0;
   if (a.bz) {
     if (taps == 9) return wide ? launch_conv<9, 64, true>(a, s) : launch_conv<9, 32, true>(a, s);
-    return wide ? launch_conv<1, 64, true>(a, s) : launch_conv<1, 32, true>(a, s);
+    if (wide) return deep ? launch_conv<1, 64, true, 64>(a, s) : launch_conv<1, 64, true>(a, s);
+    return launch_conv<1, 32, true>(a, s);
   }
   if (taps == 9) return wide ? launch_conv<9, 64, false>(a, s) : launch_conv<9, 32, false>(a, s);
-  return wide ? launch_conv<1, 64, false>(a, s) : launch_conv<1, 32, false>(a, s);
+  if (wide) return deep ? launch_conv<1, 64, false, 64>(a, s) : launch_conv<1, 64, false>(a, s);
+  return launch_conv<1, 32, false>(a, s);
 }
 
 // ---------------------------------------------------------------------------
