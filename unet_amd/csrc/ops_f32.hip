@@ -196,17 +196,23 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float *__restrict
   }
 }
 
-// One thread per channel: sums the S partials in double, writes the pair, and
-// (training forward only) updates the running statistics.
-__global__ void bn_finalize_kernel(const float *__restrict__ partial, float *__restrict__ out2,
-                                   float *__restrict__ running, int C, int S, float M) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+// One wavefront per channel: lanes sum strided slices of the S partials in double, a fixed-order
+// butterfly combines them; lane 0 writes the pair and (training forward only) updates the running
+// statistics.
+__global__ __launch_bounds__(64) void bn_finalize_kernel(const float *__restrict__ partial, float *__restrict__ out2,
+                                                         float *__restrict__ running, int C, int S, float M) {
+  const int c = blockIdx.x, lane = threadIdx.x;
   double a = 0, b = 0;
-  for (int s = 0; s < S; ++s) {
+  for (int s = lane; s < S; s += 64) {
     a += partial[((i64)c * S + s) * 2];
     b += partial[((i64)c * S + s) * 2 + 1];
   }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    a += __shfl_xor(a, o, 64);
+    b += __shfl_xor(b, o, 64);
+  }
+  if (lane != 0) return;
   out2[2 * c] = (float)a;
   out2[2 * c + 1] = (float)b;
   if (running) {
@@ -558,7 +564,7 @@ int unet_batch_norm_train_f32(const float *inputs, float *activations, const flo
   hipLaunchKernelGGL(bn_partial_kernel<0>, dim3(S, C), dim3(256), 0, as_stream(s), inputs,
                      (const float *)nullptr, (const float *)nullptr, (float *)ws, C, HW, M, S);
   UNET_LAUNCH_CHECK("bn_partial_kernel<0>");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv_u(C, 64)), dim3(64), 0, as_stream(s), (const float *)ws,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)C), dim3(64), 0, as_stream(s), (const float *)ws,
                      BN_batch_stats, BN_running_stats, C, S, (float)M);
   UNET_LAUNCH_CHECK("bn_finalize_kernel");
   hipLaunchKernelGGL(bn_apply_kernel<0>, bn_apply_grid(HW, (i64)N * C), dim3(256), 0, as_stream(s), inputs,
@@ -596,7 +602,7 @@ int unet_batch_norm_backward_f32(const float *grad_activations, const float *inp
   hipLaunchKernelGGL(bn_partial_kernel<1>, dim3(S, C), dim3(256), 0, as_stream(s), inputs, grad_activations,
                      BN_batch_stats, (float *)ws, C, HW, M, S);
   UNET_LAUNCH_CHECK("bn_partial_kernel<1>");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv_u(C, 64)), dim3(64), 0, as_stream(s), (const float *)ws,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)C), dim3(64), 0, as_stream(s), (const float *)ws,
                      grad_weights, (float *)nullptr, C, S, (float)M);
   UNET_LAUNCH_CHECK("bn_finalize_kernel");
   hipLaunchKernelGGL(bn_apply_kernel<2>, bn_apply_grid(HW, (i64)N * C), dim3(256), 0, as_stream(s), inputs,
