@@ -294,6 +294,27 @@ int unet_conv3x3_bf16(const uint16_t *in, int in_ld, const uint16_t *w_packed, c
                       uint16_t *out, int out_ld, float *stat_partials, int N, int H, int W, int CiP, int CoP,
                       int accumulate, unet_stream_t stream);
 int unet_conv3x3_stat_tiles(int H, int W);
+
+/* The segmentation head: 3x3 / pad 1 / stride 1 convolution with ONE output channel (the last CONV_LAYER of
+ * main.py:187-224; replaces cudaConvolve / cudaConvolveBackward, cuda_lib.h:44-256, for that layer).  The
+ * one-channel tensor is fp32 [N][H][W] -- the layout of the fp32 BN / sigmoid / loss entry points -- so the head needs
+ * no layout conversion and no channel padding.  CiP (padded input channels) must be 32, 64 or 128
+ * (unet_conv3x3_head_supported); other widths use unet_conv3x3_bf16.
+ *   unet_conv3x3_head_bf16        out[n,y,x] = bias[0] + sum in[n,y+kh-1,x+kw-1,ci] * W[ci][0][kh][kw];
+ *                                 w_packed = the forward operand of unet_pack_weights_bf16 ([tap][CoP][CiP])
+ *   unet_conv3x3_head_dgrad_bf16  dx (NHWC bf16, CiP channels) from dz (fp32) and the fp32 weights w [Ci][1][3][3];
+ *                                 with bn_z != NULL also the BN-backward pixel reduction of the layer that
+ *                                 produced the head's input (arguments as unet_conv3x3_dgrad_bnred_bf16,
+ *                                 bn_first_channel = 0); accumulate adds to dx (not with bn_z)
+ *   unet_conv3x3_head_wgrad_bf16  grad_w [Ci][1][3][3] and grad_b[0] = sum dz (grad_b may be NULL), deterministic */
+int unet_conv3x3_head_supported(int CiP);
+int unet_conv3x3_head_bf16(const uint16_t *in, int in_ld, const uint16_t *w_packed, const float *bias, float *out,
+                           int N, int H, int W, int CiP, int CoP, unet_stream_t s);
+int unet_conv3x3_head_dgrad_bf16(const float *dz, const float *w, int Ci, uint16_t *dx, int dx_ld, const uint16_t *bn_z,
+                                 int bn_z_ld, const float *bn_coef, float *red_partials, int N, int H, int W, int CiP,
+                                 int accumulate, unet_stream_t s);
+int unet_conv3x3_head_wgrad_bf16(const float *dz, const uint16_t *x, int x_ld, float *grad_w, float *grad_b, int N,
+                                 int H, int W, int CiP, int Ci, unet_stream_t s);
 /* Data gradient of a 3x3 convolution whose INPUT is the output of a BN + ReLU
  * layer (fuses the first pass of cudaBatchNormBackward for that layer into the
  * data-gradient half of cudaConvolveBackward).  dx = conv(dz, w_packed_bwd) is

@@ -383,3 +383,115 @@ def test_dgrad_fused_reduction_on_second_half_of_a_concat(G, capi):
         out[name] = (dzu.float().cpu().numpy(), G.host(ggb), G.host(gbias))
     assert_close(out["fused"][1], out["sep"][1], rtol=1e-4, atol_scale=1e-5, what="dgamma/dbeta")
     assert_close_bf16(out["fused"][0], out["sep"][0], what="dz")
+
+
+HEAD_CASES = [
+    # n, ci, h, w
+    (2, 64, 32, 32),
+    (1, 64, 21, 37),     # ragged tiles
+    (2, 32, 16, 16),
+    (1, 100, 18, 16),    # C_in padded 100 -> 128
+]
+
+
+@pytest.mark.parametrize("cfg", HEAD_CASES)
+def test_one_channel_head_forward_dgrad_wgrad(G, capi, oracle, cfg):
+    """The segmentation head's kernels (one output channel, fp32 [N][H][W] on the narrow side) against the
+    CPU oracle's convolution: forward, data gradient (plain, accumulate) and weight + bias gradient."""
+    n, ci, h, w = cfg
+    cip = pad32(ci)
+    assert capi.lib().unet_conv3x3_head_supported(cip) == 1
+    rng = np.random.default_rng(ci + h)
+    x = bf16_round(rng.standard_normal((n, ci, h, w)))
+    wt = bf16_round(rng.standard_normal(ci * 9) * (1.0 / np.sqrt(9 * ci)))
+    bias = np.array([0.37], np.float32)
+    w_and_b = np.concatenate([wt, bias]).astype(np.float32)
+    dz = rng.standard_normal((n, 1, h, w)).astype(np.float32)
+
+    xt = to_nhwc(G, capi, x)
+    fwd, _ = pack(G, capi, wt, ci, 1, 3)
+    z = G.empty((n, 1, h, w))
+    capi.unet_conv3x3_head_bf16(G.p(xt), cip, G.p(fwd), G.p(G.dev(bias)), G.p(z), n, h, w, cip, 32, None)
+    z_ref = oracle.convolve(x, w_and_b, 1, 3, 1, 1)
+    assert_close(G.host(z), z_ref, rtol=1e-4, atol_scale=1e-5, what=f"head forward {cfg}")
+
+    dx_ref, dw_ref = oracle.convolve_backward(x, dz, w_and_b, 3, 1, 1)
+    dzd, wd = G.dev(dz), G.dev(wt)
+    dx = torch.full((n, h, w, cip), float("nan"), dtype=torch.bfloat16, device=G.DEV)
+    capi.unet_conv3x3_head_dgrad_bf16(G.p(dzd), G.p(wd), ci, G.p(dx), cip, None, 0, None, None, n, h, w, cip, 0, None)
+    assert_close_bf16(from_nhwc(G, capi, dx, ci), dx_ref, what=f"head dgrad {cfg}")
+    assert np.all(dx.float().cpu().numpy()[..., ci:] == 0), "padded gradient channels must be zero"
+    capi.unet_conv3x3_head_dgrad_bf16(G.p(dzd), G.p(wd), ci, G.p(dx), cip, None, 0, None, None, n, h, w, cip, 1, None)
+    assert_close_bf16(from_nhwc(G, capi, dx, ci), 2 * dx_ref, what=f"head dgrad accumulate {cfg}")
+
+    gw, gb = G.empty((ci * 9,)), G.empty((1,))
+    capi.unet_conv3x3_head_wgrad_bf16(G.p(dzd), G.p(xt), cip, G.p(gw), G.p(gb), n, h, w, cip, ci, None)
+    assert_close(G.host(gw), dw_ref[:ci * 9], rtol=1e-4, atol_scale=1e-5, what=f"head wgrad {cfg}")
+    assert_close(G.host(gb), dw_ref[ci * 9:], rtol=1e-4, atol_scale=1e-5, what=f"head bias gradient {cfg}")
+
+
+def test_one_channel_head_dgrad_with_fused_bn_reduction(G, capi):
+    """With bn_z the head's data-gradient kernel also emits the BN-backward partial sums of the layer below:
+    same dx and same (dgamma, dbeta, dz) as the unfused pair of calls."""
+    n, ci, h, w = 2, 64, 24, 40
+    rng = np.random.default_rng(5)
+    dz = G.dev(rng.standard_normal((n, 1, h, w)).astype(np.float32))
+    wt = G.dev((rng.standard_normal(ci * 9) * 0.1).astype(np.float32))
+    zp = torch.from_numpy(rng.standard_normal((n, h, w, ci)).astype(np.float32)).to(G.DEV).bfloat16()
+    gbp = G.dev((rng.random(2 * ci) + 0.5).astype(np.float32))
+    coef = G.dev(np.stack([rng.random(ci) + 0.5, rng.standard_normal(ci) * 0.3, rng.standard_normal(ci) * 0.1,
+                           rng.random(ci) + 0.7], axis=1).astype(np.float32).reshape(-1))
+    pixels, tiles = n * h * w, capi.lib().unet_conv3x3_stat_tiles(h, w)
+    dx_a = torch.zeros((n, h, w, ci), dtype=torch.bfloat16, device=G.DEV)
+    dx_b = torch.zeros_like(dx_a)
+    parts = G.empty((n * tiles * ci * 2,))
+    capi.unet_conv3x3_head_dgrad_bf16(G.p(dz), G.p(wt), ci, G.p(dx_a), ci, None, 0, None, None, n, h, w, ci, 0, None)
+    capi.unet_conv3x3_head_dgrad_bf16(G.p(dz), G.p(wt), ci, G.p(dx_b), ci, G.p(zp), ci, G.p(coef), G.p(parts), n, h, w,
+                                      ci, 0, None)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(dx_a.float().cpu().numpy(), dx_b.float().cpu().numpy())
+    out = {}
+    for name in ("sep", "fused"):
+        dzp = torch.zeros((n, h, w, ci), dtype=torch.bfloat16, device=G.DEV)
+        ggb, gbias = G.empty((2 * ci,)), G.empty((ci,))
+        if name == "fused":
+            capi.unet_bn_act_backward_from_partials_bf16(G.p(dx_a), ci, G.p(zp), ci, G.p(coef), G.p(gbp), G.p(parts),
+                                                         n * tiles, G.p(dzp), ci, G.p(ggb), G.p(gbias), ci, ci, pixels, None)
+        else:
+            capi.unet_bn_act_backward_bf16(G.p(dx_a), ci, None, 0, G.p(zp), ci, G.p(coef), G.p(gbp), G.p(dzp), ci, G.p(ggb),
+                                           G.p(gbias), ci, ci, pixels, 0, None)
+        torch.cuda.synchronize()
+        out[name] = (dzp.float().cpu().numpy(), G.host(ggb))
+    assert_close(out["fused"][1], out["sep"][1], rtol=1e-4, atol_scale=1e-5, what="dgamma/dbeta")
+    assert_close_bf16(out["fused"][0], out["sep"][0], what="dz")
+
+
+def test_first_layer_with_8_stored_channels(G, capi, oracle):
+    """A 3-channel image stored as NHWC with 8 channels (16 bytes per pixel): the forward and weight-gradient
+    entry points take CiP = 8 with weights packed for 32 and give what the 32-channel storage gives."""
+    n, ci, co, h, w = 2, 3, 64, 37, 21
+    rng = np.random.default_rng(3)
+    x = bf16_round(rng.standard_normal((n, ci, h, w)))
+    wt = bf16_round(rng.standard_normal(ci * co * 9) * 0.2)
+    bias = (rng.standard_normal(co) * 0.5).astype(np.float32)
+    dy = bf16_round(rng.standard_normal((n, co, h, w)))
+    fwd, _ = pack(G, capi, wt, ci, co, 3)
+    bd = G.dev(bias)
+    x8, x32 = to_nhwc(G, capi, x, ld=8, cpad=8), to_nhwc(G, capi, x, ld=32, cpad=32)
+    np.testing.assert_array_equal(x8.float().cpu().numpy()[..., :ci], x.transpose(0, 2, 3, 1))
+    assert np.all(x8.float().cpu().numpy()[..., ci:] == 0)
+    outs = []
+    for xt, cp in ((x8, 8), (x32, 32)):
+        out = torch.zeros((n, h, w, co), dtype=torch.bfloat16, device=G.DEV)
+        capi.unet_conv3x3_bf16(G.p(xt), cp, G.p(fwd), G.p(bd), co, G.p(out), co, None, n, h, w, cp, co, 0, None)
+        outs.append(from_nhwc(G, capi, out, co))
+    np.testing.assert_array_equal(outs[0], outs[1])
+    assert_close_bf16(outs[0], oracle.convolve(x, np.concatenate([wt, bias]).astype(np.float32), co, 3, 1, 1),
+                      what="first layer forward")
+    dyt = to_nhwc(G, capi, dy)
+    gws = []
+    for xt, cp in ((x8, 8), (x32, 32)):
+        gw = G.empty((ci * co * 9,))
+        capi.unet_conv3x3_wgrad_bf16(G.p(dyt), co, G.p(xt), cp, G.p(gw), n, h, w, cp, co, ci, co, None)
+        gws.append(G.host(gw))
+    np.testing.assert_array_equal(gws[0], gws[1])

@@ -1,5 +1,5 @@
 """Per-(kernel, grid) launch counts and mean durations from a rocprofv3 kernel-trace CSV.
-usage: python tools/trace_by_shape.py <kernel_trace.csv> [steps] [name filter regex]"""
+usage: python tools/trace_by_shape.py <kernel_trace.csv> [steps | 0 = last step only] [name filter regex]"""
 import collections
 import csv
 import re
@@ -7,6 +7,11 @@ import sys
 
 rows = list(csv.DictReader(open(sys.argv[1])))
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+if steps == 0:  # only the last full training step: the launches between the last two optimiser kernels
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    idx = [i for i, r in enumerate(rows) if "adam_kernel" in r["Kernel_Name"]]
+    rows = rows[idx[-2] + 1:idx[-1] + 1]
+    steps = 1
 filt = re.compile(sys.argv[3]) if len(sys.argv) > 3 else None
 g = collections.defaultdict(list)
 for r in rows:

@@ -60,6 +60,7 @@ enum UnetProfKind {
   PROF_BN_BWD_REDUCE_BF16, // bn_bwd_reduce_kernel
   PROF_BN_BWD_APPLY_BF16,  // bn_bwd_apply_kernel
   PROF_POOL_BF16,
+  PROF_CONV_HEAD_BF16,     // head_fwd / head_dgrad / head_wgrad kernels (one-channel 3x3 convolution)
   PROF_KINDS
 };
 bool unet_prof_on();

@@ -57,6 +57,8 @@ struct ConvArgs {
   const bf16_t *bz;
   int bz_ld;
   const float4 *bcf;
+  int in_c;     // > 0: input channels present in memory (multiple of 8, < 32, single K chunk); pieces beyond
+                // it are taken as zero without touching memory (first layer: 3 image channels stored as 8)
   int bred_c0;  // output channels below this one take no part (the other half of a concat's gradient);
                 // bz, bcf and stats are indexed by (channel - bred_c0), stats rows hold CoP - bred_c0 channels
 };
@@ -102,7 +104,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
     const int c = tid + 256 * i, pix = c / PPR, part = c % PPR;
     const int py = pix / HALO, px = pix - py * HALO;
     const int y = y0 + py - (TAPS == 9), x = x0 + px - (TAPS == 9);
-    const bool ok = c < XCH && y >= 0 && y < a.Ho && x >= 0 && x < a.Wo;
+    const bool ok = c < XCH && y >= 0 && y < a.Ho && x >= 0 && x < a.Wo && (a.in_c == 0 || part * 8 < a.in_c);
     const int iy = (TAPS == 9) ? y : y * a.in_s + a.in_oy, ix = (TAPS == 9) ? x : x * a.in_s + a.in_ox;
     xoff[i] = ok ? (iy * a.Win + ix) * a.in_ld + part * 8 : -1;
   }
@@ -435,6 +437,20 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float *__restri
   }
 }
 
+// The same for at most 8 channels stored as exactly 8 (ld = 8): one thread per pixel, coalesced plane reads,
+// one 16-byte store.
+__global__ __launch_bounds__(256) void nchw_to_nhwc8_kernel(const float *__restrict__ in, bf16_t *__restrict__ out, int C,
+                                                            i64 HW) {
+  const i64 n = blockIdx.y;
+  const i64 p = (i64)blockIdx.x * 256 + threadIdx.x;
+  if (p >= HW) return;
+  uint32_t h[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) h[c] = c < C ? f32_to_bf16(in[(n * C + c) * HW + p]) : 0u;
+  *reinterpret_cast<uint4 *>(out + (n * HW + p) * 8) =
+      make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
+}
+
 // NHWC bf16 (pixel stride ld) -> NCHW fp32, channels [0, C)
 __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const bf16_t *__restrict__ in, float *__restrict__ out,
                                                            int C, i64 HW, int ld) {
@@ -480,6 +496,11 @@ int unet_nchw_f32_to_nhwc_bf16(const float *in, uint16_t *out, int N, int C, int
   UNET_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0 && Cpad >= C && ld >= Cpad && N <= 65535,
                "unet_nchw_f32_to_nhwc_bf16: bad sizes");
   const i64 HW = (i64)H * W;
+  if (Cpad == 8 && ld == 8 && ((uintptr_t)out & 15) == 0) {
+    hipLaunchKernelGGL(nchw_to_nhwc8_kernel, dim3(cdiv_u(HW, 256), (unsigned)N), dim3(256), 0, as_stream(s), in, out, C, HW);
+    UNET_LAUNCH_CHECK("nchw_to_nhwc8_kernel");
+    return UNET_OK;
+  }
   dim3 grid(cdiv_u(HW, 32), cdiv_u(Cpad, 32), (unsigned)N);
   hipLaunchKernelGGL(nchw_to_nhwc_kernel, grid, dim3(256), 0, as_stream(s), in, out, C, HW, ld, Cpad);
   UNET_LAUNCH_CHECK("nchw_to_nhwc_kernel");
@@ -502,11 +523,14 @@ int unet_conv3x3_bf16(const uint16_t *in, int in_ld, const uint16_t *w_packed, c
                       int accumulate, unet_stream_t s) {
   UNET_REQUIRE(in && w_packed && out, "unet_conv3x3_bf16: NULL pointer");
   UNET_REQUIRE(N > 0 && N <= 65535 && H > 0 && W > 0, "unet_conv3x3_bf16: bad sizes");
-  UNET_REQUIRE(CiP > 0 && CiP % 32 == 0 && CoP > 0 && CoP % 32 == 0 && in_ld >= CiP && out_ld >= CoP &&
-                   in_ld % 8 == 0 && out_ld % 8 == 0,
-               "unet_conv3x3_bf16: channel counts must be multiples of 32 and pixel strides multiples of 8");
+  UNET_REQUIRE(CiP > 0 && (CiP % 32 == 0 || (CiP < 32 && CiP % 8 == 0)) && CoP > 0 && CoP % 32 == 0 && in_ld >= CiP &&
+                   out_ld >= CoP && in_ld % 8 == 0 && out_ld % 8 == 0,
+               "unet_conv3x3_bf16: CiP must be a multiple of 32 (or 8, 16, 24 with weights packed for 32), CoP a "
+               "multiple of 32, pixel strides multiples of 8");
   UNET_REQUIRE((((uintptr_t)in | (uintptr_t)out | (uintptr_t)w_packed) & 15) == 0,
                "unet_conv3x3_bf16: pointers must be 16-byte aligned");
+  const int in_present = CiP < 32 ? CiP : 0;  // fewer than 32 input channels in memory: one K chunk, tail pieces zero
+  if (CiP < 32) CiP = 32;
   UNET_REQUIRE((i64)H * W * in_ld < (1ll << 31) && (i64)H * W * out_ld < (1ll << 31),
                "unet_conv3x3_bf16: one image must stay below 2^31 elements");
   ConvArgs a{};
@@ -517,6 +541,7 @@ int unet_conv3x3_bf16(const uint16_t *in, int in_ld, const uint16_t *w_packed, c
   a.tilesX = (W + 15) / 16;
   a.co_valid = co_valid;
   a.out_phases = a.k_phases = 1;
+  a.in_c = in_present;
   const double flops = 2.0 * N * H * W * (double)CiP * CoP * 9;
   ProfScope prof(stat_partials || bias ? PROF_CONV_FWD_BF16 : PROF_CONV_DGRAD_BF16, flops,
                  2.0 * N * H * W * ((double)CiP + CoP), as_stream(s));

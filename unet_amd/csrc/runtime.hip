@@ -87,7 +87,7 @@ const char *kProfNames[PROF_KINDS] = {
     "conv_fwd_f32",      "conv_dgrad_f32",     "conv_wgrad_f32",     "tconv_f32",
     "batch_norm_f32",    "conv3x3_fwd_bf16",   "conv3x3_dgrad_bf16", "conv3x3_wgrad_bf16",
     "wgrad_reduce",      "tconv2x2_bf16",      "tconv2x2_wgrad_bf16", "bn_act_bf16",
-    "bn_bwd_reduce_bf16", "bn_bwd_apply_bf16", "pool_bf16"};
+    "bn_bwd_reduce_bf16", "bn_bwd_apply_bf16", "pool_bf16",         "conv3x3_head_bf16"};
 hipEvent_t prof_event() {
   if (!g_prof_pool.empty()) {
     hipEvent_t e = g_prof_pool.back();

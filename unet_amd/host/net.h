@@ -111,6 +111,7 @@ struct Node {
   // ---- bf16 / NHWC path ----
   int cip = 0, cop = 0;          // channel counts padded to multiples of 32
   bool narrow = false;           // final layer with C_out not a multiple of 32: BN/activation/loss run in fp32
+  bool head = false;             // narrow 3x3 conv with one output channel: the dedicated head kernels apply
   DeviceBuffer zb;               // conv / tconv output before BN, [N,H,W,cop] bf16
   DeviceBuffer yb;               // activation, when it is not a slice of a concat buffer
   uint16_t *y_ptr = nullptr;     // where the activation lives ...
@@ -245,7 +246,7 @@ class Net {
     ensure_batch(batch);
     if (use_bf16_) {
       if (params_dirty_) pack_all_weights();
-      UNET_CALL(unet_nchw_f32_to_nhwc_bf16(images, x16_.u16(), batch, in_c_, in_h_, in_w_, 32, 32, stream_));
+      UNET_CALL(unet_nchw_f32_to_nhwc_bf16(images, x16_.u16(), batch, in_c_, in_h_, in_w_, in_cp(), in_cp(), stream_));
       for (Node &n : nodes_) forward_node_bf16(n, batch, inference);
       return;
     }
@@ -778,6 +779,7 @@ class Net {
     for (Node &n : nodes_) {
       n.concat_child = -1;
       n.narrow = false;
+      n.head = false;
     }
     std::vector<int> nchild(nodes_.size(), 0);
     for (size_t i = 0; i < nodes_.size(); ++i) {
@@ -823,6 +825,8 @@ class Net {
       if (n.parents.empty() && n.type != CONV_LAYER) return why = "an input layer that is not a convolution", false;
       n.cip = n.parents.empty() ? 32 : pad32(n.in_c);
       n.cop = pad32(n.out_c);
+      n.head = n.narrow && n.type == CONV_LAYER && n.out_c == 1 && !n.parents.empty() &&
+               unet_conv3x3_head_supported(n.cip) != 0;
     }
     return true;
   }
@@ -894,15 +898,20 @@ class Net {
       case CONV_LAYER:
       case UPSAMPLING_LAYER: {
         const uint16_t *in = n.parents.empty() ? x16_.u16() : nodes_[n.parents[0]].y_ptr;
-        const int in_ld = n.parents.empty() ? 32 : nodes_[n.parents[0]].y_ld;
+        const int in_ld = n.parents.empty() ? in_cp() : nodes_[n.parents[0]].y_ld;
+        const int in_cip = n.parents.empty() ? in_cp() : n.cip;  // channels present in memory
         const float *w = params_.f32() + n.param_off;
         const float *bias = w + (n.num_wb - n.out_c);
         const float *gb = w + n.num_wb;
         float *parts = (inference || n.narrow) ? nullptr : n.stat_partials.f32();
         int num_parts;
-        if (n.type == CONV_LAYER) {
+        if (n.head) {
+          UNET_CALL(unet_conv3x3_head_bf16(in, in_ld, n.w_fwd.u16(), bias, n.z.f32(), batch, n.in_h, n.in_w, n.cip, n.cop,
+                                           stream_));
+          num_parts = 0;
+        } else if (n.type == CONV_LAYER) {
           UNET_CALL(unet_conv3x3_bf16(in, in_ld, n.w_fwd.u16(), bias, n.out_c, n.zb.u16(), n.cop, parts, batch, n.in_h,
-                                      n.in_w, n.cip, n.cop, 0, stream_));
+                                      n.in_w, in_cip, n.cop, 0, stream_));
           num_parts = batch * unet_conv3x3_stat_tiles(n.in_h, n.in_w);
         } else {
           UNET_CALL(unet_tconv2x2_bf16(in, in_ld, n.w_fwd.u16(), bias, n.out_c, n.zb.u16(), n.cop, parts, batch, n.in_h,
@@ -911,7 +920,8 @@ class Net {
         }
         if (n.narrow) {
           // final layer: BN + activation (+ loss) on the fp32 kernels, [N,C,H,W] with C = out_c
-          UNET_CALL(unet_nhwc_bf16_to_nchw_f32(n.zb.u16(), n.z.f32(), batch, n.out_c, n.out_h, n.out_w, n.cop, stream_));
+          if (!n.head)
+            UNET_CALL(unet_nhwc_bf16_to_nchw_f32(n.zb.u16(), n.z.f32(), batch, n.out_c, n.out_h, n.out_w, n.cop, stream_));
           if (inference)
             UNET_CALL(unet_batch_norm_inference_f32(n.z.f32(), n.bn.f32(), gb, n.running.f32(), n.out_h, n.out_w,
                                                     n.out_c, batch, stream_));
@@ -974,6 +984,20 @@ class Net {
             UNET_CALL(unet_relu_backward_f32(n.grad_out.f32(), n.bn.f32(), g2, out_n, stream_));
           UNET_CALL(unet_batch_norm_backward_f32(g2, n.z.f32(), n.batch_stats.f32(), w + n.num_wb, g1, gw + n.num_wb,
                                                  n.out_c, n.out_h, n.out_w, batch, stream_));
+          if (n.head) {
+            // one output channel: data and weight gradients straight from the fp32 dz, on the head kernels
+            Node &p = nodes_[n.parents[0]];
+            const bool fuse = p.has_params() && !p.narrow && p.num_children == 1 && p.concat_child < 0 && !p.g_written &&
+                              !(p.type == CONV_LAYER && p.activation == SIGMOID);
+            UNET_CALL(unet_conv3x3_head_dgrad_bf16(g1, w, n.in_c, p.gb.u16(), p.cop, fuse ? p.zb.u16() : nullptr, p.cop,
+                                                   fuse ? p.coef.f32() : nullptr, fuse ? p.bwd_partials.f32() : nullptr,
+                                                   batch, n.in_h, n.in_w, n.cip, (!fuse && p.g_written) ? 1 : 0, stream_));
+            if (fuse) p.bwd_partials_n = batch * unet_conv3x3_stat_tiles(n.in_h, n.in_w);
+            p.g_written = true;
+            UNET_CALL(unet_conv3x3_head_wgrad_bf16(g1, p.y_ptr, p.y_ld, gw, gbias, batch, n.in_h, n.in_w, n.cip, n.in_c,
+                                                   stream_));
+            break;
+          }
           UNET_CALL(unet_nchw_f32_to_nhwc_bf16(g1, dz, batch, n.out_c, n.out_h, n.out_w, n.cop, n.cop, stream_));
           // bias gradient = per-channel sum of dz: reuse the BN statistics reduction (sum x lands at [2c])
           UNET_CALL(unet_batch_norm_train_f32(g1, g2, w + n.num_wb, n.coef.f32(), nullptr, n.out_c, n.out_h, n.out_w,
@@ -995,7 +1019,7 @@ class Net {
                                                 n.cop, gw + n.num_wb, gbias, n.out_c, n.cop, out_pix, act, stream_));
         }
         const uint16_t *x = n.parents.empty() ? x16_.u16() : nodes_[n.parents[0]].y_ptr;
-        const int x_ld = n.parents.empty() ? 32 : nodes_[n.parents[0]].y_ld;
+        const int x_ld = n.parents.empty() ? in_cp() : nodes_[n.parents[0]].y_ld;
         if (!n.parents.empty()) {
           Node &p = nodes_[n.parents[0]];
           // When this is the only gradient the parent's output receives and the parent is a
@@ -1031,8 +1055,8 @@ class Net {
           p.g_written = true;
         }
         if (n.type == CONV_LAYER)
-          UNET_CALL(unet_conv3x3_wgrad_bf16(dz, n.cop, x, x_ld, gw, batch, n.in_h, n.in_w, n.cip, n.cop, n.in_c, n.out_c,
-                                            stream_));
+          UNET_CALL(unet_conv3x3_wgrad_bf16(dz, n.cop, x, x_ld, gw, batch, n.in_h, n.in_w,
+                                            n.parents.empty() ? in_cp() : n.cip, n.cop, n.in_c, n.out_c, stream_));
         else
           UNET_CALL(unet_tconv2x2_wgrad_bf16(dz, n.cop, x, x_ld, gw, batch, n.in_h, n.in_w, n.cip, n.cop, n.in_c,
                                              n.out_c, stream_));
@@ -1075,6 +1099,8 @@ class Net {
   LossFunction loss_ = LossFunction::kDiceLoss;
   int final_ = -1;
   int in_c_ = 0, in_h_ = 0, in_w_ = 0;
+  // channels of the network input as stored in x16_: 8 for up to 8 image channels (16 bytes per pixel), else 32
+  int in_cp() const { return in_c_ <= 8 ? 8 : 32; }
   int64_t total_params_ = 0;
   DeviceBuffer params_, grads_, adam_;
   DeviceBuffer scratch_g1_, scratch_g2_, scratch_dx_;
@@ -1084,7 +1110,7 @@ class Net {
   uint64_t seed_ = 0;
   bool params_dirty_ = true;
   bool use_bf16_ = false;
-  DeviceBuffer x16_;      // network input as NHWC bf16, channels padded to 32
+  DeviceBuffer x16_;      // network input as NHWC bf16, channels padded to in_cp()
   DeviceBuffer dz16_;     // scratch: gradient w.r.t. a layer's pre-BN output
   bool verbose_ = true;
   unet_stream_t stream_ = nullptr;
