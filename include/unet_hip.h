@@ -278,6 +278,11 @@ int unet_scale_f32(float *x, float alpha, int64_t num_elements, unet_stream_t st
  * convolution).  Either output may be NULL. */
 int unet_pack_weights_bf16(const float *w_ref, uint16_t *w_fwd, uint16_t *w_bwd, int Ci, int Co, int CiP,
                            int CoP, int K, unet_stream_t stream);
+/* The same for every layer of a network in one launch.  table_device (device memory) holds `layers` rows of ten
+ * 64-bit integers {w_ref, w_fwd, w_bwd (addresses), Ci, Co, CiP, CoP, K, first_box, 0}: first_box = number of
+ * 32x32 channel boxes, (CiP/32)*(CoP/32) per layer, of the rows before; total_boxes = their sum over all rows.
+ * Per row the arguments mean what they mean for unet_pack_weights_bf16. */
+int unet_pack_weights_batch_bf16(const int64_t *table_device, int layers, int total_boxes, unet_stream_t stream);
 /* NCHW fp32 -> NHWC bf16 (pixel stride ld); channels [C, Cpad) are zeroed. */
 int unet_nchw_f32_to_nhwc_bf16(const float *in, uint16_t *out, int N, int C, int H, int W, int ld, int Cpad,
                                unet_stream_t stream);

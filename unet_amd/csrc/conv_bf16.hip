@@ -371,12 +371,10 @@ int launch_conv_any(int taps, const ConvArgs &a, hipStream_t s) {
 // into LDS, then each lane packs 8 consecutive bf16 and stores 16 bytes: 64-byte runs along ci (fwd)
 // and along co (bwd).
 template <int K>
-__global__ __launch_bounds__(256) void pack_weights_kernel(const float *__restrict__ w, bf16_t *__restrict__ fwd,
-                                                           bf16_t *__restrict__ bwd, int Ci, int Co, int CiP,
-                                                           int CoP) {
+__device__ __forceinline__ void pack_box(const float *__restrict__ w, bf16_t *__restrict__ fwd, bf16_t *__restrict__ bwd,
+                                         int Ci, int Co, int CiP, int CoP, int box_x, int box_y, float *tile) {
   constexpr int taps = K * K, run = 32 * taps, pitch = run + 1;
-  __shared__ float tile[32 * pitch];
-  const int ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32;
+  const int ci0 = box_x * 32, co0 = box_y * 32;
   const bool full = ci0 + 32 <= Ci && co0 + 32 <= Co && (Co * taps) % 4 == 0 && (reinterpret_cast<uintptr_t>(w) & 15) == 0;
   if (full) {
     for (int idx = threadIdx.x; idx < 32 * (run / 4); idx += 256) {
@@ -413,6 +411,36 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float *__restri
       *reinterpret_cast<uint4 *>(bwd + ((i64)tb * CiP + ci0 + b) * CoP + co0 + a) = make_uint4(v[0], v[1], v[2], v[3]);
     }
   }
+}
+
+template <int K>
+__global__ __launch_bounds__(256) void pack_weights_kernel(const float *__restrict__ w, bf16_t *__restrict__ fwd,
+                                                           bf16_t *__restrict__ bwd, int Ci, int Co, int CiP,
+                                                           int CoP) {
+  __shared__ float tile[32 * (32 * K * K + 1)];
+  pack_box<K>(w, fwd, bwd, Ci, Co, CiP, CoP, blockIdx.x, blockIdx.y, tile);
+}
+
+// All layers of a network in one launch.  table[l] = {w_ref, w_fwd, w_bwd, Ci, Co, CiP, CoP, K, first_box, 0}
+// (pointers as 64-bit integers); workgroup b serves the layer with first_box <= b < next first_box.
+constexpr int PACK_ROW = 10;
+__global__ __launch_bounds__(256) void pack_weights_batch_kernel(const int64_t *__restrict__ table, int layers) {
+  __shared__ float tile[32 * (32 * 9 + 1)];
+  const int b = blockIdx.x;
+  int lo = 0, hi = layers - 1;  // last layer with first_box <= b
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (table[mid * PACK_ROW + 8] <= b) lo = mid; else hi = mid - 1;
+  }
+  const int64_t *r = table + lo * PACK_ROW;
+  const float *w = reinterpret_cast<const float *>(r[0]);
+  bf16_t *fwd = reinterpret_cast<bf16_t *>(r[1]), *bwd = reinterpret_cast<bf16_t *>(r[2]);
+  const int Ci = (int)r[3], Co = (int)r[4], CiP = (int)r[5], CoP = (int)r[6], K = (int)r[7];
+  const int box = b - (int)r[8], bx = box % (CiP / 32), by = box / (CiP / 32);
+  if (K == 3)
+    pack_box<3>(w, fwd, bwd, Ci, Co, CiP, CoP, bx, by, tile);
+  else
+    pack_box<2>(w, fwd, bwd, Ci, Co, CiP, CoP, bx, by, tile);
 }
 
 // NCHW fp32 -> NHWC bf16 with pixel stride ld; channels [C, Cpad) are zero-filled.
@@ -487,6 +515,13 @@ int unet_pack_weights_bf16(const float *w_ref, uint16_t *w_fwd, uint16_t *w_bwd,
   else
     hipLaunchKernelGGL(pack_weights_kernel<2>, grid, dim3(256), 0, as_stream(s), w_ref, w_fwd, w_bwd, Ci, Co, CiP, CoP);
   UNET_LAUNCH_CHECK("pack_weights_kernel");
+  return UNET_OK;
+}
+
+int unet_pack_weights_batch_bf16(const int64_t *table_device, int layers, int total_boxes, unet_stream_t s) {
+  UNET_REQUIRE(table_device && layers > 0 && total_boxes > 0, "unet_pack_weights_batch_bf16: bad arguments");
+  hipLaunchKernelGGL(pack_weights_batch_kernel, dim3((unsigned)total_boxes), dim3(256), 0, as_stream(s), table_device, layers);
+  UNET_LAUNCH_CHECK("pack_weights_batch_kernel");
   return UNET_OK;
 }
 

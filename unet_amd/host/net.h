@@ -236,6 +236,7 @@ class Net {
       UNET_CALL(unet_memset(n.running.raw(), 0, sizeof(float), stream_));
     }
     params_dirty_ = true;
+    pack_boxes_ = 0;
   }
 
   // ---- training step pieces (device pointers, nothing synchronises) --------
@@ -881,14 +882,34 @@ class Net {
     in_masks_.ensure(sizeof(float) * b * (size_t)f.out_h * f.out_w);
     loss_values_.ensure(sizeof(float) * 3 * b);
     params_dirty_ = true;
+    pack_boxes_ = 0;
   }
 
   // fp32 master weights [C_in][C_out][k][k] -> packed bf16 operands
+  // One launch for all layers; the table of per-layer arguments lives on the device and is rebuilt
+  // whenever buffers may have moved (ensure_batch_bf16 clears pack_boxes_).
   void pack_all_weights() {
-    for (Node &n : nodes_)
-      if (n.has_params())
-        UNET_CALL(unet_pack_weights_bf16(params_.f32() + n.param_off, n.w_fwd.u16(), n.w_bwd.u16(), n.in_c, n.out_c,
-                                         n.cip, n.cop, n.type == CONV_LAYER ? 3 : 2, stream_));
+    if (pack_boxes_ == 0) {
+      std::vector<int64_t> table;
+      int64_t boxes = 0;
+      pack_layers_ = 0;
+      for (Node &n : nodes_)
+        if (n.has_params()) {
+          const int64_t row[10] = {(int64_t)(uintptr_t)(params_.f32() + n.param_off), (int64_t)(uintptr_t)n.w_fwd.u16(),
+                                   (int64_t)(uintptr_t)n.w_bwd.u16(), n.in_c, n.out_c, n.cip, n.cop,
+                                   n.type == CONV_LAYER ? 3 : 2, boxes, 0};
+          table.insert(table.end(), row, row + 10);
+          boxes += (int64_t)(n.cip / 32) * (n.cop / 32);
+          ++pack_layers_;
+        }
+      if (pack_layers_ == 0) { params_dirty_ = false; return; }
+      pack_table_.ensure(sizeof(int64_t) * table.size());
+      UNET_CALL(unet_memcpy_h2d(pack_table_.raw(), table.data(), sizeof(int64_t) * table.size(), stream_));
+      UNET_CALL(unet_stream_synchronize(stream_));  // `table` is a local
+      pack_boxes_ = (int)boxes;
+    }
+    UNET_CALL(unet_pack_weights_batch_bf16(reinterpret_cast<const int64_t *>(pack_table_.raw()), pack_layers_, pack_boxes_,
+                                           stream_));
     params_dirty_ = false;
   }
 
@@ -1109,6 +1130,8 @@ class Net {
   int step_count_ = 0;
   uint64_t seed_ = 0;
   bool params_dirty_ = true;
+  DeviceBuffer pack_table_;  // per-layer arguments of the batched weight packing
+  int pack_layers_ = 0, pack_boxes_ = 0;
   bool use_bf16_ = false;
   DeviceBuffer x16_;      // network input as NHWC bf16, channels padded to in_cp()
   DeviceBuffer dz16_;     // scratch: gradient w.r.t. a layer's pre-BN output
