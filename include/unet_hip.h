@@ -257,6 +257,12 @@ int unet_update_weights_sgd_f32(float *weights, const float *dLdW, float learnin
 int unet_add_b_to_a_f32(float *a, const float *b, int64_t num_floats, unet_stream_t stream);
 /* Replaces cudaThreshold: x = x >= t ? 1 : 0. */
 int unet_threshold_f32(float *x, float threshold, int64_t num_elements, unet_stream_t stream);
+/* Raw image input (no counterpart in the reference, whose caller normalises on the host, main.py:85-98):
+ * uint8 [N][H][W][C] -> fp32 [N][C][H][W] with out = in*scale[c] + shift[c] (scale, shift in device memory);
+ * uint8 -> fp32 with one scale (masks stored as 0/255). */
+int unet_normalize_u8_nhwc_to_nchw_f32(const uint8_t *in, float *out, const float *scale, const float *shift, int N,
+                                       int C, int H, int W, unet_stream_t stream);
+int unet_u8_to_f32(const uint8_t *in, float *out, int64_t num_elements, float scale, unet_stream_t stream);
 /* x *= alpha (gradient averaging across data-parallel ranks). */
 int unet_scale_f32(float *x, float alpha, int64_t num_elements, unet_stream_t stream);
 

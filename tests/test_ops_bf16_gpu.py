@@ -411,7 +411,8 @@ def test_one_channel_head_forward_dgrad_wgrad(G, capi, oracle, cfg):
     xt = to_nhwc(G, capi, x)
     fwd, _ = pack(G, capi, wt, ci, 1, 3)
     z = G.empty((n, 1, h, w))
-    capi.unet_conv3x3_head_bf16(G.p(xt), cip, G.p(fwd), G.p(G.dev(bias)), G.p(z), n, h, w, cip, 32, None)
+    bd = G.dev(bias)
+    capi.unet_conv3x3_head_bf16(G.p(xt), cip, G.p(fwd), G.p(bd), G.p(z), n, h, w, cip, 32, None)
     z_ref = oracle.convolve(x, w_and_b, 1, 3, 1, 1)
     assert_close(G.host(z), z_ref, rtol=1e-4, atol_scale=1e-5, what=f"head forward {cfg}")
 

@@ -284,6 +284,23 @@ inline int bn_splits(i64 M, int C) {
   return (int)s;
 }
 
+// ---- raw image input ---------------------------------------------------------------
+// uint8 [N][H][W][C] (the layout image files decode to) -> fp32 [N][C][H][W], out = in*scale[c] + shift[c]:
+// the /255 and per-channel z-score of main.py:89-92 done on the device, so a batch crosses PCIe as bytes.
+__global__ __launch_bounds__(256) void normalize_u8_nhwc_kernel(const uint8_t *__restrict__ in, float *__restrict__ out,
+                                                                const float *__restrict__ scale,
+                                                                const float *__restrict__ shift, int C, i64 HW) {
+  const i64 n = blockIdx.y;
+  const i64 p = (i64)blockIdx.x * 256 + threadIdx.x;
+  if (p >= HW) return;
+  const uint8_t *src = in + (n * HW + p) * C;
+  for (int c = 0; c < C; ++c) out[(n * C + c) * HW + p] = fmaf((float)src[c], scale[c], shift[c]);
+}
+__global__ __launch_bounds__(256) void u8_to_f32_kernel(const uint8_t *__restrict__ in, float *__restrict__ out, i64 n,
+                                                        float scale) {
+  for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < n; i += (i64)gridDim.x * 256) out[i] = (float)in[i] * scale;
+}
+
 // ---- max pool -------------------------------------------------------------------
 __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float *__restrict__ x,
                                                           float *__restrict__ y,
@@ -477,6 +494,24 @@ int unet_sigmoid_backward_f32(const float *grad_activations, const float *activa
 }
 int unet_add_b_to_a_f32(float *a, const float *b, int64_t n, unet_stream_t s) {
   return launch_ew2(a, b, a, n, AddF(), s, "unet_add_b_to_a_f32");
+}
+int unet_normalize_u8_nhwc_to_nchw_f32(const uint8_t *in, float *out, const float *scale, const float *shift, int N,
+                                       int C, int H, int W, unet_stream_t s) {
+  UNET_REQUIRE(in && out && scale && shift, "unet_normalize_u8_nhwc_to_nchw_f32: NULL pointer");
+  UNET_REQUIRE(N > 0 && N <= 65535 && C > 0 && H > 0 && W > 0, "unet_normalize_u8_nhwc_to_nchw_f32: bad sizes");
+  const i64 HW = (i64)H * W;
+  hipLaunchKernelGGL(normalize_u8_nhwc_kernel, dim3(cdiv_u(HW, 256), (unsigned)N), dim3(256), 0, as_stream(s), in, out,
+                     scale, shift, C, HW);
+  UNET_LAUNCH_CHECK("normalize_u8_nhwc_kernel");
+  return UNET_OK;
+}
+int unet_u8_to_f32(const uint8_t *in, float *out, int64_t n, float scale, unet_stream_t s) {
+  UNET_REQUIRE(in && out && n > 0, "unet_u8_to_f32: bad arguments");
+  const i64 blocks = (n + 255) / 256;
+  hipLaunchKernelGGL(u8_to_f32_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, as_stream(s), in,
+                     out, (i64)n, scale);
+  UNET_LAUNCH_CHECK("u8_to_f32_kernel");
+  return UNET_OK;
 }
 int unet_threshold_f32(float *x, float threshold, int64_t n, unet_stream_t s) {
   return launch_ew1(x, x, n, ThreshF{threshold}, s, "unet_threshold_f32");

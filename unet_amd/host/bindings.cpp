@@ -43,6 +43,16 @@ class NN {
     if (batch_size < 1) throw std::runtime_error("Batch size must be greater than 0");
     const float *img = static_cast<const float *>(ii.ptr);
     const float *msk = static_cast<const float *>(mi.ptr);
+    run_epochs(N, batch_size, epochs, learning_rate, [&](int slot, int64_t start, int count) {
+      net_.stage_batch_host(slot, img + start * C * H * W, msk + start * H * W, count);
+    });
+  }
+
+  // The epoch loop of train(): batch b+1 is staged (host copy to pinned memory, then an asynchronous
+  // transfer on a second stream) while the GPU runs batch b.  stage(slot, first image, count).
+  template <typename Stage>
+  void run_epochs(int64_t N, int batch_size, int epochs, float learning_rate, Stage stage) {
+    const bool v = net_.verbose();
     if (v) std::cout << "initiating gradient parameters" << std::endl;
     net_.ensure_batch(batch_size);
     if (v) std::cout << "done init_gradient_parameters" << std::endl;
@@ -53,17 +63,14 @@ class NN {
     for (int epoch = 0; epoch < epochs; ++epoch) {
       if (v) std::cout << "beggining epoch " << epoch << "/" << epochs << std::endl;
       const auto t0 = std::chrono::steady_clock::now();
-      // batch b+1 is staged (host copy to pinned memory, then an asynchronous transfer on a second
-      // stream) while the GPU runs batch b
-      net_.stage_batch_host(0, img, msk, (int)std::min<int64_t>(batch_size, N));
+      stage(0, 0, (int)std::min<int64_t>(batch_size, N));
       for (int64_t b = 0; b < nb; ++b) {
         const int64_t start = b * batch_size;
         const int cur = (int)std::min<int64_t>(batch_size, N - start);
         net_.train_batch_staged((int)(b & 1), learning_rate, true);
         if (b + 1 < nb) {
           const int64_t nstart = start + batch_size;
-          net_.stage_batch_host((int)((b + 1) & 1), img + nstart * C * H * W, msk + nstart * H * W,
-                                (int)std::min<int64_t>(batch_size, N - nstart));
+          stage((int)((b + 1) & 1), nstart, (int)std::min<int64_t>(batch_size, N - nstart));
         }
         if (net_.loss() == LossFunction::kDiceLoss)
           UNET_CALL(unet_memcpy_d2d(epoch_lv.f32() + 3 * (size_t)batch_size * b, net_.loss_values_ptr(),
@@ -92,7 +99,48 @@ class NN {
     }
   }
 
-  // neural_net.h:45-67: one image [C,H,W] -> thresholded mask (1,H,W).
+  // ---- byte-input feed (additive): raw uint8 images [N,H,W,C] and uint8 masks [N,H,W]; the /255 and
+  // per-channel z-score of main.py:89-92 run on the device, masks are scaled by 1/255 when they hold 0/255
+  // (main.py:97-98)
+  typedef py::array_t<uint8_t, py::array::c_style | py::array::forcecast> u8array;
+  void set_input_normalization(farray mean, farray stddev) {
+    if (mean.size() != stddev.size()) throw std::runtime_error("mean and std must have one entry per channel");
+    net_.set_input_normalization(mean.data(), stddev.data(), (int)mean.size());
+  }
+  static float mask_scale_of(const uint8_t *m, size_t n) {
+    for (size_t i = 0; i < n; ++i)
+      if (m[i] > 1) return 1.0f / 255.0f;
+    return 1.0f;
+  }
+  void train_u8(u8array images, u8array masks, float learning_rate, int epochs, int batch_size) {
+    py::buffer_info ii = images.request(), mi = masks.request();
+    if (ii.ndim != 4) throw std::runtime_error("images must have shape [N, H, W, C]");
+    if (mi.ndim != 3) throw std::runtime_error("masks must have shape [N, H, W]");
+    const int64_t N = ii.shape[0], H = ii.shape[1], W = ii.shape[2], C = ii.shape[3];
+    if (N != mi.shape[0] || H != mi.shape[1] || W != mi.shape[2])
+      throw std::runtime_error("Mask dimensions do not equal image dimensions");
+    check_input(C, H, W);
+    if (batch_size < 1) throw std::runtime_error("Batch size must be greater than 0");
+    const uint8_t *img = static_cast<const uint8_t *>(ii.ptr), *msk = static_cast<const uint8_t *>(mi.ptr);
+    const float ms = mask_scale_of(msk, (size_t)mi.size);
+    run_epochs(N, batch_size, epochs, learning_rate, [&](int slot, int64_t start, int count) {
+      net_.stage_batch_host_u8(slot, img + start * H * W * C, msk + start * H * W, count, ms);
+    });
+  }
+  py::array_t<float> infer_u8(u8array image) {
+    py::buffer_info ii = image.request();
+    if (ii.ndim != 3) throw std::runtime_error("Only accepting single images [H, W, C]");
+    check_input(ii.shape[2], ii.shape[0], ii.shape[1]);
+    const unet::Node &f = net_.nodes()[net_.final_layer()];
+    std::vector<uint8_t> no_mask((size_t)f.out_h * f.out_w, 0);
+    net_.stage_batch_host_u8(0, static_cast<const uint8_t *>(ii.ptr), no_mask.data(), 1, 1.0f);
+    net_.infer_batch_staged(0);
+    UNET_CALL(unet_threshold_f32(const_cast<float *>(f.act.f32()), 0.5f, f.out_elems(), net_.stream()));
+    py::array_t<float> ret({(py::ssize_t)f.out_c, (py::ssize_t)f.out_h, (py::ssize_t)f.out_w});
+    net_.copy_output_to_host(net_.final_layer(), ret.mutable_data(), 1);
+    return ret;
+  }
+
   py::array_t<float> infer(farray image) {
     py::buffer_info ii = image.request();
     if (ii.ndim != 3) throw std::runtime_error("Only accepting single images");
@@ -355,6 +403,9 @@ PYBIND11_MODULE(neural_net, m) {
       .def("create", &NN::create)
       .def("train", &NN::train)
       .def("infer", &NN::infer)
+      .def("set_input_normalization", &NN::set_input_normalization)
+      .def("train_u8", &NN::train_u8)
+      .def("infer_u8", &NN::infer_u8)
       .def("test", &NN::test)
       // additive
       .def("set_seed", &NN::set_seed)

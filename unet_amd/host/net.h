@@ -351,6 +351,66 @@ class Net {
     sl.in_use = true;
     sl.batch = batch;
   }
+  // Per-channel input normalisation of the byte feed: x -> (x/255 - mean[c]) / (std[c] + 1e-7)  (main.py:89-92)
+  void set_input_normalization(const float *mean, const float *stddev, int channels) {
+    require_created();
+    if (channels != in_c_) throw std::runtime_error("set_input_normalization: one mean / std per input channel");
+    std::vector<float> coef(2 * (size_t)channels);
+    for (int c = 0; c < channels; ++c) {
+      const float inv = 1.0f / (stddev[c] + 1e-7f);
+      coef[c] = inv / 255.0f;
+      coef[channels + c] = -mean[c] * inv;
+    }
+    norm_coef_.ensure(sizeof(float) * coef.size());
+    UNET_CALL(unet_memcpy_h2d(norm_coef_.raw(), coef.data(), sizeof(float) * coef.size(), stream_));
+    sync();  // `coef` is a local
+    norm_set_ = true;
+  }
+  // The same double-buffered feed for raw images: uint8 [N][H][W][C] images and uint8 masks cross PCIe as
+  // bytes (a quarter of the fp32 volume); the copy stream then normalises them into the slot's fp32 buffers.
+  void stage_batch_host_u8(int slot, const uint8_t *images, const uint8_t *masks, int batch, float mask_scale) {
+    ensure_batch(batch);
+    if (!norm_set_) throw std::runtime_error("stage_batch_host_u8: call set_input_normalization first");
+    InputSlot &sl = slots_[slot & 1];
+    const Node &f = nodes_[final_];
+    const size_t ie = (size_t)batch * in_c_ * in_h_ * in_w_, me = (size_t)batch * f.out_h * f.out_w;
+    if (!copy_stream_) UNET_CALL(unet_stream_create(&copy_stream_));
+    if (!sl.copied) {
+      UNET_CALL(unet_event_create(&sl.copied));
+      UNET_CALL(unet_event_create(&sl.consumed));
+    }
+    if (sl.pinned_bytes < ie + me) {
+      if (sl.pinned) {
+        UNET_CALL(unet_event_synchronize(sl.copied));
+        UNET_CALL(unet_host_free(sl.pinned));
+      }
+      UNET_CALL(unet_host_malloc(&sl.pinned, ie + me));
+      sl.pinned_bytes = ie + me;
+    }
+    sl.images.ensure(sizeof(float) * ie);
+    sl.masks.ensure(sizeof(float) * me);
+    sl.raw.ensure(ie + me);
+    if (sl.in_use) UNET_CALL(unet_event_synchronize(sl.copied));  // the pinned buffer is free again
+    std::memcpy(sl.pinned, images, ie);
+    std::memcpy(static_cast<char *>(sl.pinned) + ie, masks, me);
+    if (sl.in_use) UNET_CALL(unet_stream_wait_event(copy_stream_, sl.consumed));  // device buffers no longer read
+    UNET_CALL(unet_memcpy_h2d(sl.raw.raw(), sl.pinned, ie + me, copy_stream_));
+    const uint8_t *raw = static_cast<const uint8_t *>(sl.raw.raw());
+    UNET_CALL(unet_normalize_u8_nhwc_to_nchw_f32(raw, sl.images.f32(), norm_coef_.f32(), norm_coef_.f32() + in_c_, batch,
+                                                 in_c_, in_h_, in_w_, copy_stream_));
+    UNET_CALL(unet_u8_to_f32(raw + ie, sl.masks.f32(), (int64_t)me, mask_scale, copy_stream_));
+    UNET_CALL(unet_event_record(sl.copied, copy_stream_));
+    sl.in_use = true;
+    sl.batch = batch;
+  }
+  // Forward pass (inference) on a staged batch; the output is read with the usual getters.
+  void infer_batch_staged(int slot) {
+    InputSlot &sl = slots_[slot & 1];
+    if (!sl.in_use) throw std::runtime_error("infer_batch_staged: the slot holds no batch");
+    UNET_CALL(unet_stream_wait_event(stream_, sl.copied));
+    forward_device(sl.images.f32(), sl.batch, true);
+    UNET_CALL(unet_event_record(sl.consumed, stream_));
+  }
   // One training step on a staged batch; returns the device pointer of its masks' loss sums owner.
   void train_batch_staged(int slot, float lr, bool do_step) {
     InputSlot &sl = slots_[slot & 1];
@@ -1108,13 +1168,15 @@ class Net {
   struct InputSlot {
     void *pinned = nullptr;
     size_t pinned_bytes = 0;
-    DeviceBuffer images, masks;
+    DeviceBuffer images, masks, raw;  // raw: the uint8 batch of the byte-input feed
     unet_event_t copied = nullptr, consumed = nullptr;
     bool in_use = false;
     int batch = 0;
   };
   InputSlot slots_[2];
   unet_stream_t copy_stream_ = nullptr;
+  DeviceBuffer norm_coef_;  // [scale(C) | shift(C)] of the byte-input feed
+  bool norm_set_ = false;
 
   std::vector<Node> nodes_;
   LossFunction loss_ = LossFunction::kDiceLoss;
