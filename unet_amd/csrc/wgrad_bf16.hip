@@ -253,7 +253,10 @@ static int run_wgrad(int taps, int phases, const WgradArgs &base, float *grad, i
   // every workgroup writes a 64 x 64 x taps fp32 partial block, so the number of workgroups sets the
   // partial-sum traffic: one per CU for the 3x3 filters (147 KB each; measured faster in sum with the
   // reduction than two per CU), two per CU for the 16 KB blocks of the transposed convolution
-  const int target_blocks = taps == 9 ? 256 : 512;
+  // -- unless a workgroup's pixel slice is long anyway (large images): then the partials are negligible
+  // and two workgroups per CU hide each other's staging
+  const bool long_slices = (i64)a.total_chunks * tiles >= (i64)48 * 512;
+  const int target_blocks = (taps == 9 && !long_slices) ? 256 : 512;
   int splits = (target_blocks / phases + tiles - 1) / tiles;
   if (splits > a.total_chunks) splits = a.total_chunks;
   if (splits < 1) splits = 1;
