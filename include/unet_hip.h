@@ -277,11 +277,12 @@ int unet_scale_f32(float *x, float alpha, int64_t num_elements, unet_stream_t st
  * cudaRelu, cudaReluBackward + cudaBatchNormBackward, ...); their fp32
  * one-to-one counterparts are above. */
 
-/* w_ref [Ci][Co][K][K] fp32 (reference layout) -> packed bf16, zero padded:
- *   w_fwd [K*K][CoP][CiP]            (forward operand)
- *   w_bwd [K*K][CiP][CoP], taps flipped for K=3 (data-gradient operand)
- * K = 3 (convolution) or 2 (the four phases of the 2x2 transposed
- * convolution).  Either output may be NULL. */
+/* w_ref [Ci][Co][K][K] fp32 (reference layout) -> packed bf16 operands, zero padded, K*K*CoP*CiP elements each:
+ *   K = 3 (convolution):  w_fwd [CiP/32][9][CoP][32]  (32-channel K chunks outermost),
+ *                         w_bwd [CoP/32][9][CiP][32], taps flipped (data-gradient operand)
+ *   K = 2 (the four phases of the 2x2 transposed convolution): w_fwd [4][CoP][CiP], w_bwd [4][CiP][CoP]
+ * The layouts are what the convolution entry points below read; treat the buffers as opaque.
+ * Either output may be NULL. */
 int unet_pack_weights_bf16(const float *w_ref, uint16_t *w_fwd, uint16_t *w_bwd, int Ci, int Co, int CiP,
                            int CoP, int K, unet_stream_t stream);
 /* The same for every layer of a network in one launch.  table_device (device memory) holds `layers` rows of ten
@@ -312,7 +313,7 @@ int unet_conv3x3_stat_tiles(int H, int W);
  * no layout conversion and no channel padding.  CiP (padded input channels) must be 32, 64 or 128
  * (unet_conv3x3_head_supported); other widths use unet_conv3x3_bf16.
  *   unet_conv3x3_head_bf16        out[n,y,x] = bias[0] + sum in[n,y+kh-1,x+kw-1,ci] * W[ci][0][kh][kw];
- *                                 w_packed = the forward operand of unet_pack_weights_bf16 ([tap][CoP][CiP])
+ *                                 w_packed = the forward operand of unet_pack_weights_bf16 (K = 3)
  *   unet_conv3x3_head_dgrad_bf16  dx (NHWC bf16, CiP channels) from dz (fp32) and the fp32 weights w [Ci][1][3][3];
  *                                 with bn_z != NULL also the BN-backward pixel reduction of the layer that
  *                                 produced the head's input (arguments as unet_conv3x3_dgrad_bnred_bf16,

@@ -131,8 +131,12 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
       const int c = tid + 256 * i, row = c / PPR, part = c % PPR;
       const int tap = row / BN, co = row % BN;
       wr[i] = make_uint4(0, 0, 0, 0);
-      if (WCH % 256 == 0 || c < WCH)
-        wr[i] = *reinterpret_cast<const uint4 *>(w_thread + ((i64)tap * a.CoP + co) * a.Ci + wo + part * 8);
+      if (WCH % 256 == 0 || c < WCH) {
+        if (TAPS == 9)  // chunk-major operand: the whole 9 x BN x 32 slab of chunk kc is contiguous per channel block
+          wr[i] = *reinterpret_cast<const uint4 *>(wt + (((i64)kc * TAPS + tap) * a.CoP + co0 + co) * 32 + part * 8);
+        else
+          wr[i] = *reinterpret_cast<const uint4 *>(w_thread + ((i64)tap * a.CoP + co) * a.Ci + wo + part * 8);
+      }
     }
   };
   auto store_chunk = [&]() {
@@ -364,9 +368,11 @@ int launch_conv_any(int taps, const ConvArgs &a, hipStream_t s) {
 // Weight packing and layout conversion.
 // ---------------------------------------------------------------------------
 // w_ref [Ci][Co][K][K] fp32 ->
-//   fwd [tap][CoP][CiP] bf16 (tap = kh*K+kw), zero padded
-//   bwd [tap][CiP][CoP] bf16 with flipped taps for K=3 (data gradient as a forward conv over dZ);
-//       unflipped for the transposed-conv phases (K=2, taps are the (i,j) phases)
+//   K=3: fwd [CiP/32][tap][CoP][32] bf16 (tap = kh*3+kw, zero padded): the 32-channel K chunks of the
+//        conv kernel's main loop are the outer index, so the slab a workgroup stages per chunk is
+//        contiguous runs of whole cache lines;
+//        bwd [CoP/32][tap][CiP][32] with flipped taps (data gradient as a forward conv over dZ)
+//   K=2: fwd [phase][CoP][CiP], bwd [phase][CiP][CoP] (the (i,j) phases of the transposed conv)
 // A workgroup moves a 32(ci) x 32(co) x taps box: contiguous 16-byte reads of the reference layout
 // into LDS, then each lane packs 8 consecutive bf16 and stores 16 bytes: 64-byte runs along ci (fwd)
 // and along co (bwd).
@@ -399,7 +405,9 @@ __device__ __forceinline__ void pack_box(const float *__restrict__ w, bf16_t *__
       for (int j = 0; j < 4; ++j)
         v[j] = f32_to_bf16(tile[(a + 2 * j) * pitch + b * taps + t]) |
                (f32_to_bf16(tile[(a + 2 * j + 1) * pitch + b * taps + t]) << 16);
-      *reinterpret_cast<uint4 *>(fwd + ((i64)t * CoP + co0 + b) * CiP + ci0 + a) = make_uint4(v[0], v[1], v[2], v[3]);
+      bf16_t *dst = (K == 3) ? fwd + (((i64)box_x * taps + t) * CoP + co0 + b) * 32 + a   // [ci chunk][tap][co][32]
+                             : fwd + ((i64)t * CoP + co0 + b) * CiP + ci0 + a;            // [phase][co][ci]
+      *reinterpret_cast<uint4 *>(dst) = make_uint4(v[0], v[1], v[2], v[3]);
     }
     if (bwd) {  // a = first of 8 consecutive co, b = ci
       const int tb = (K == 3) ? (taps - 1 - t) : t;
@@ -408,7 +416,9 @@ __device__ __forceinline__ void pack_box(const float *__restrict__ w, bf16_t *__
       for (int j = 0; j < 4; ++j)
         v[j] = f32_to_bf16(tile[b * pitch + (a + 2 * j) * taps + t]) |
                (f32_to_bf16(tile[b * pitch + (a + 2 * j + 1) * taps + t]) << 16);
-      *reinterpret_cast<uint4 *>(bwd + ((i64)tb * CiP + ci0 + b) * CoP + co0 + a) = make_uint4(v[0], v[1], v[2], v[3]);
+      bf16_t *dst = (K == 3) ? bwd + (((i64)box_y * taps + tb) * CiP + ci0 + b) * 32 + a  // [co chunk][tap][ci][32]
+                             : bwd + ((i64)tb * CiP + ci0 + b) * CoP + co0 + a;           // [phase][ci][co]
+      *reinterpret_cast<uint4 *>(dst) = make_uint4(v[0], v[1], v[2], v[3]);
     }
   }
 }

@@ -22,7 +22,7 @@ constexpr int HALO = 18, NPIX = HALO * HALO;
 // ---------------------------------------------------------------------------------------------
 template <int CI>  // padded input channels
 __global__ __launch_bounds__(256) void head_fwd_kernel(const bf16_t *__restrict__ in, int in_ld,
-                                                       const uint32_t *__restrict__ wt,  // [tap][CoP][CI] bf16, row co = 0 used
+                                                       const uint32_t *__restrict__ wt,  // [CI/32][tap][CoP][32] bf16, rows co = 0 used
                                                        int w_tap_stride_dw, const float *__restrict__ bias,
                                                        float *__restrict__ out, int H, int W, int tilesX) {
   constexpr int PPR = CI / 8, PITCH = CI * 2 + 16, PIECES = NPIX * PPR;
@@ -45,14 +45,15 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const bf16_t *__restrict_
 #pragma unroll
   for (int tap = 0; tap < 9; ++tap) {
     const unsigned char *row = lds + ((ty + tap / 3) * HALO + tx + tap % 3) * PITCH;
-    const uint32_t *wrow = wt + (i64)tap * w_tap_stride_dw;  // uniform: scalar loads
 #pragma unroll
     for (int p = 0; p < PPR; ++p) {
+      // operand layout [ci chunk of 32][tap][CoP][32]: row (chunk p/4, tap, co = 0); uniform -> scalar loads
+      const uint32_t *wrow = wt + ((i64)(p / 4) * 9 + tap) * w_tap_stride_dw + (p % 4) * 4;
       const uint4 v = *reinterpret_cast<const uint4 *>(row + p * 16);
-      acc0 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, v.x), __builtin_bit_cast(bf16x2, wrow[p * 4 + 0]), acc0, false);
-      acc1 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, v.y), __builtin_bit_cast(bf16x2, wrow[p * 4 + 1]), acc1, false);
-      acc0 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, v.z), __builtin_bit_cast(bf16x2, wrow[p * 4 + 2]), acc0, false);
-      acc1 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, v.w), __builtin_bit_cast(bf16x2, wrow[p * 4 + 3]), acc1, false);
+      acc0 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, v.x), __builtin_bit_cast(bf16x2, wrow[0]), acc0, false);
+      acc1 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, v.y), __builtin_bit_cast(bf16x2, wrow[1]), acc1, false);
+      acc0 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, v.z), __builtin_bit_cast(bf16x2, wrow[2]), acc0, false);
+      acc1 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, v.w), __builtin_bit_cast(bf16x2, wrow[3]), acc1, false);
     }
   }
   const int y = y0 + ty, x = x0 + tx;
@@ -303,7 +304,7 @@ int unet_conv3x3_head_bf16(const uint16_t *in, int in_ld, const uint16_t *w_pack
   const int tilesX = (W + 15) / 16, tiles = tilesX * ((H + 15) / 16);
   const size_t lds = (size_t)NPIX * (CiP * 2 + 16);
   const uint32_t *wt = reinterpret_cast<const uint32_t *>(w_packed);
-  const int tap_stride = CoP * CiP / 2;
+  const int tap_stride = CoP * 32 / 2;  // dwords between consecutive (chunk, tap) rows
   ProfScope prof(PROF_CONV_HEAD_BF16, 2.0 * N * H * W * (double)CiP * 9, (double)N * H * W * (2.0 * CiP + 4.0), as_stream(s));
   dim3 grid((unsigned)tiles, (unsigned)N);
   static bool done32[64], done64[64], done128[64];
