@@ -26,3 +26,33 @@ __device__ __forceinline__ bf16x8 tr_read_pair(const unsigned char *p0, const un
   const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
   return __builtin_bit_cast(bf16x8, v);
 }
+
+// Sum over the lanes of a wavefront that share (lane % CH), CH a power of two in [4, 32]; every lane gets
+// the total.  Built from DPP row rotations and the gfx950 lane-swap instructions: no LDS traffic, unlike
+// __shfl_xor (ds_bpermute_b32), whose round trips queue behind a co-resident workgroup's fragment reads.
+__device__ __forceinline__ float lane_rot_sum8(float v) {  // + lane (i + 8) % 16 of the same 16-lane row
+  return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float lane_rot_sum4(float v) {  // + lane (i + 4) % 16 of the same 16-lane row
+  return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float lane_swap_sum16(float v) {  // + lane i ^ 16
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float lane_swap_sum32(float v) {  // + lane i ^ 32
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+template <int CH>
+__device__ __forceinline__ float lane_class_sum(float v) {
+  static_assert(CH == 4 || CH == 8 || CH == 16 || CH == 32, "lane_class_sum: CH must be 4, 8, 16 or 32");
+  if (CH <= 4) {
+    v = lane_rot_sum8(v);  // {i, i+8}
+    v = lane_rot_sum4(v);  // {i, i+4, i+8, i+12}: the row's lanes of this class
+  } else if (CH <= 8) {
+    v = lane_rot_sum8(v);
+  }
+  if (CH <= 16) v = lane_swap_sum16(v);
+  return lane_swap_sum32(v);
+}

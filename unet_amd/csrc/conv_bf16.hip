@@ -296,15 +296,13 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
     for (int j = 0; j < 8; ++j) ssum[j] = (ssum[j] - bcf[j].z * ssq[j]) * bcf[j].w;
   }
   if (BRED ? red_here : (stats != nullptr)) {
-    // lanes with equal (lane % CH) hold the same 8 channels: butterfly over the other lane bits,
+    // lanes with equal (lane % CH) hold the same 8 channels: sum over them (VALU cross-lane ops),
     // then one partial per wave through LDS, summed in wave order (deterministic)
 #pragma unroll
-    for (int o = CH; o < 64; o <<= 1)
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        ssum[j] += __shfl_xor(ssum[j], o, 64);
-        ssq[j] += __shfl_xor(ssq[j], o, 64);
-      }
+    for (int j = 0; j < 8; ++j) {
+      ssum[j] = lane_class_sum<CH>(ssum[j]);
+      ssq[j] = lane_class_sum<CH>(ssq[j]);
+    }
     float *red = reinterpret_cast<float *>(lds + 256 * OP);  // [wave][BN][2]
     if (lane < CH) {
 #pragma unroll

@@ -158,12 +158,10 @@ __global__ __launch_bounds__(256) void head_dgrad_kernel(const float *__restrict
     for (int j = 0; j < 4; ++j) ssum[j] = (ssum[j] - cf[j].z * ssq[j]) * cf[j].w;
     // lanes with equal (lane % CH) hold the same channels
 #pragma unroll
-    for (int o = CH; o < 64; o <<= 1)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        ssum[j] += __shfl_xor(ssum[j], o, 64);
-        ssq[j] += __shfl_xor(ssq[j], o, 64);
-      }
+    for (int j = 0; j < 4; ++j) {
+      ssum[j] = lane_class_sum<CH>(ssum[j]);
+      ssq[j] = lane_class_sum<CH>(ssq[j]);
+    }
     if (lane < CH) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
