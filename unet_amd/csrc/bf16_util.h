@@ -28,21 +28,15 @@ __device__ __forceinline__ bf16x8 tr_read_pair(const unsigned char *p0, const un
 }
 
 // Sum over the lanes of a wavefront that share (lane % CH), CH a power of two in [4, 32]; every lane gets
-// the total.  Built from DPP row rotations and the gfx950 lane-swap instructions: no LDS traffic, unlike
-// __shfl_xor (ds_bpermute_b32), whose round trips queue behind a co-resident workgroup's fragment reads.
+// the total.  The stages inside a 16-lane row are DPP row rotations (VALU, no LDS traffic); the two stages
+// across rows are __shfl_xor (ds_bpermute_b32).  The gfx950 lane-swap instructions (v_permlane16/32_swap)
+// would make those VALU-only as well and measured 0.4 % faster on the whole step, but the sums then varied
+// from run to run (with the builtins and with inline asm plus wait states alike), so they are not used.
 __device__ __forceinline__ float lane_rot_sum8(float v) {  // + lane (i + 8) % 16 of the same 16-lane row
   return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xf, 0xf, true));
 }
 __device__ __forceinline__ float lane_rot_sum4(float v) {  // + lane (i + 4) % 16 of the same 16-lane row
   return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124, 0xf, 0xf, true));
-}
-__device__ __forceinline__ float lane_swap_sum16(float v) {  // + lane i ^ 16
-  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
-__device__ __forceinline__ float lane_swap_sum32(float v) {  // + lane i ^ 32
-  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 template <int CH>
 __device__ __forceinline__ float lane_class_sum(float v) {
@@ -53,6 +47,6 @@ __device__ __forceinline__ float lane_class_sum(float v) {
   } else if (CH <= 8) {
     v = lane_rot_sum8(v);
   }
-  if (CH <= 16) v = lane_swap_sum16(v);
-  return lane_swap_sum32(v);
+  if (CH <= 16) v += __shfl_xor(v, 16, 64);
+  return v + __shfl_xor(v, 32, 64);
 }
