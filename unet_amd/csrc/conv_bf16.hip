@@ -66,9 +66,15 @@ struct ConvArgs {
 // KC = channels staged per main-loop trip: 32 for the 3x3 kernels (the 9-tap weight slab sets the LDS
 // budget); 64 for the 1x1 kernels when the channel count allows, whose trips are otherwise too short to
 // cover a load's latency
-template <int TAPS, int BN, bool BRED, int KC>
+// MMA = 0: v_mfma_f32_32x32x16_bf16, LDS rows padded by 16 bytes.  MMA = 1 (3x3 kernels, KC = 32):
+// v_mfma_f32_16x16x32_bf16 -- one instruction consumes a whole 32-channel chunk of a 16x16 output block --
+// over dense 64-byte LDS rows whose 16-byte pieces are XOR-swizzled by (row >> 1) & 3, which makes every
+// fragment read conflict-free and the staging buffers 20 % smaller; the chip also holds a higher clock on
+// this MFMA shape.  3-5 % faster on every layer shape but the 16x16-pixel images (one workgroup per CU).
+template <int TAPS, int BN, bool BRED, int KC, int MMA = 0>
 __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
-  constexpr int PITCH = KC * 2 + 16;  // bytes per LDS row of KC bf16; the 16-byte pad spreads rows over the banks
+  static_assert(MMA == 0 || (TAPS == 9 && KC == 32), "the 16x16x32 path is written for the 3x3 kernels");
+  constexpr int PITCH = MMA ? 64 : KC * 2 + 16;  // bytes per LDS row of KC bf16 (MMA 0: + 16-byte pad)
   constexpr int PPR = KC / 8;         // 16-byte pieces per row
   constexpr int HALO = (TAPS == 9) ? 18 : 16;
   constexpr int NPIX = HALO * HALO;
@@ -143,25 +149,48 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
 #pragma unroll
     for (int i = 0; i < XI; ++i) {
       const int c = tid + 256 * i;
-      if (XCH % 256 == 0 || c < XCH) *reinterpret_cast<uint4 *>(ldsX + (c / PPR) * PITCH + (c % PPR) * 16) = xr[i];
+      const int row = c / PPR, slot = MMA ? ((c % PPR) ^ ((row >> 1) & 3)) : (c % PPR);
+      if (XCH % 256 == 0 || c < XCH) *reinterpret_cast<uint4 *>(ldsX + row * PITCH + slot * 16) = xr[i];
     }
 #pragma unroll
     for (int i = 0; i < WI; ++i) {
       const int c = tid + 256 * i;
-      if (WCH % 256 == 0 || c < WCH) *reinterpret_cast<uint4 *>(ldsW + (c / PPR) * PITCH + (c % PPR) * 16) = wr[i];
+      const int row = c / PPR, slot = MMA ? ((c % PPR) ^ ((row >> 1) & 3)) : (c % PPR);
+      if (WCH % 256 == 0 || c < WCH) *reinterpret_cast<uint4 *>(ldsW + row * PITCH + slot * 16) = wr[i];
     }
   };
 
-  f32x16 acc[MF][2];
+  constexpr int MB = BN / 16;  // MMA 1: 16-channel blocks
+  f32x16 acc[MMA ? 1 : MF][MMA ? 1 : 2];  // MMA 0: [32-channel block][32-pixel block]
+  f32x4 acc4[MMA ? MB : 1][MMA ? 4 : 1];  // MMA 1: [16-channel block][pixel row of the wave]
 #pragma unroll
-  for (int m = 0; m < MF; ++m)
+  for (int m = 0; m < (MMA ? 1 : MF); ++m)
 #pragma unroll
-    for (int q = 0; q < 2; ++q)
+    for (int q = 0; q < (MMA ? 1 : 2); ++q)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[m][q][r] = 0.f;
+#pragma unroll
+  for (int m = 0; m < (MMA ? MB : 1); ++m)
+#pragma unroll
+    for (int q = 0; q < (MMA ? 4 : 1); ++q) acc4[m][q] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int a_lane = (lane & 31) * PITCH + (lane >> 5) * 16;
   const int b_lane = ((wave * 4 + ((lane & 31) >> 4)) * HALO + (lane & 15)) * PITCH + (lane >> 5) * 16;
+  // MMA 1 fragments: lane = (row or pixel l15, 8-channel part kp) of a 16 x 32 block
+  const int l15 = lane & 15, kp = lane >> 4;
+  const int a4_lane = l15 * 64 + ((kp ^ ((l15 >> 1) & 3)) * 16);
+  // pixel fragments: halo index p = row*18 + col + kw with row = 4*wave + q + kh; the swizzle term
+  // (p >> 1) & 3 depends only on (row & 3) and on (col + kw) -- wave*4*18 is a multiple of 8
+  int b4_off[MMA ? 3 : 1][MMA ? 4 : 1];
+  if (MMA) {
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+      for (int rc = 0; rc < 4; ++rc) {
+        const int pl = rc * HALO + l15 + kw;
+        b4_off[MMA ? kw : 0][MMA ? rc : 0] = (l15 + kw) * 64 + ((kp ^ ((pl >> 1) & 3)) * 16) + wave * 4 * HALO * 64;
+      }
+  }
 
   // bias of this workgroup's channels: one global load per thread into LDS (behind the staging buffers),
   // read back as broadcast 16-byte pieces in the epilogue
@@ -178,6 +207,22 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
 #pragma unroll
     for (int tap = 0; tap < TAPS; ++tap) {
       const int kh = (TAPS == 9) ? tap / 3 : 0, kw = (TAPS == 9) ? tap % 3 : 0;
+      if (MMA) {
+        bf16x8 af[MB], bfr[4];
+#pragma unroll
+        for (int m = 0; m < MB; ++m)
+          af[m] = *reinterpret_cast<const bf16x8 *>(ldsW + (tap * BN + m * 16) * 64 + a4_lane);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          bfr[q] = *reinterpret_cast<const bf16x8 *>(ldsX + (q + kh) * HALO * 64 + b4_off[MMA ? kw : 0][MMA ? ((q + kh) & 3) : 0]);
+#pragma unroll
+        for (int m = 0; m < MB; ++m)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            acc4[MMA ? m : 0][MMA ? q : 0] =
+                __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[m], bfr[q], acc4[MMA ? m : 0][MMA ? q : 0], 0, 0, 0);
+        continue;
+      }
 #pragma unroll
       for (int ks = 0; ks < KC / 16; ++ks) {
         bf16x8 af[MF], bfr[2];
@@ -225,20 +270,32 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
             rc0 + (tid % CHB) * 8);
     }
   }
+  if (MMA) {
 #pragma unroll
-  for (int m = 0; m < MF; ++m)
+    for (int m = 0; m < MB; ++m)
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const int pix = wave * 64 + q * 32 + (lane & 31);
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int ch = m * 32 + 8 * g + 4 * (lane >> 5);
-        f32x4 v = {acc[m][q][4 * g], acc[m][q][4 * g + 1], acc[m][q][4 * g + 2], acc[m][q][4 * g + 3]};
+      for (int q = 0; q < 4; ++q) {
+        const int pix = (wave * 4 + q) * 16 + l15, ch = m * 16 + 4 * kp;
+        f32x4 v = acc4[MMA ? m : 0][MMA ? q : 0];
         if (!BRED) v += *reinterpret_cast<const f32x4 *>(ldsB + ch);
-        const bf16x4 h = __builtin_convertvector(v, bf16x4);
-        *reinterpret_cast<bf16x4 *>(stage + pix * OP + ch * 2) = h;
+        *reinterpret_cast<bf16x4 *>(stage + pix * OP + ch * 2) = __builtin_convertvector(v, bf16x4);
       }
-    }
+  } else {
+#pragma unroll
+    for (int m = 0; m < MF; ++m)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int pix = wave * 64 + q * 32 + (lane & 31);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int ch = m * 32 + 8 * g + 4 * (lane >> 5);
+          f32x4 v = {acc[m][q][4 * g], acc[m][q][4 * g + 1], acc[m][q][4 * g + 2], acc[m][q][4 * g + 3]};
+          if (!BRED) v += *reinterpret_cast<const f32x4 *>(ldsB + ch);
+          const bf16x4 h = __builtin_convertvector(v, bf16x4);
+          *reinterpret_cast<bf16x4 *>(stage + pix * OP + ch * 2) = h;
+        }
+      }
+  }
   __syncthreads();
 
   // ---- staging tile -> HBM, 16 bytes per lane, whole channel rows; the same pass
@@ -322,36 +379,39 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
   }
 }
 
-template <int TAPS, int BN, int KC>
+template <int TAPS, int BN, int KC, int MMA = 0>
 constexpr size_t conv_lds_bytes() {
   constexpr int HALO = (TAPS == 9) ? 18 : 16;
-  constexpr int PITCH = KC * 2 + 16;
+  constexpr int PITCH = MMA ? 64 : KC * 2 + 16;
   constexpr size_t main_loop = (size_t)TAPS * BN * PITCH + (size_t)HALO * HALO * PITCH;
   constexpr size_t epilogue = (size_t)256 * (BN * 2 + 16) + 2048;
   return (main_loop > epilogue ? main_loop : epilogue) + BN * sizeof(float);  // + the bias vector
 }
 
-template <int TAPS, int BN, bool BRED, int KC = 32>
+template <int TAPS, int BN, bool BRED, int KC = 32, int MMA = 0>
 int launch_conv(const ConvArgs &a, hipStream_t s) {
   static bool attr_set[64] = {};
-  constexpr size_t lds = conv_lds_bytes<TAPS, BN, KC>();
+  constexpr size_t lds = conv_lds_bytes<TAPS, BN, KC, MMA>();
   int dev = 0;
   UNET_HIP_TRY(hipGetDevice(&dev));
   if (!attr_set[dev & 63]) {
-    UNET_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_mfma_kernel<TAPS, BN, BRED, KC>),
+    UNET_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_mfma_kernel<TAPS, BN, BRED, KC, MMA>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set[dev & 63] = true;
   }
   const int tilesY = (a.Ho + 15) / 16;
   dim3 grid((unsigned)(tilesY * a.tilesX), (unsigned)(a.CoP / BN * (a.out_phases > 1 ? a.out_phases : 1)),
             (unsigned)a.N);
-  hipLaunchKernelGGL((conv_mfma_kernel<TAPS, BN, BRED, KC>), grid, dim3(256), lds, s, a);
+  hipLaunchKernelGGL((conv_mfma_kernel<TAPS, BN, BRED, KC, MMA>), grid, dim3(256), lds, s, a);
   UNET_LAUNCH_CHECK("conv_mfma_kernel");
   return UNET_OK;
 }
 
 int launch_conv_any(int taps, const ConvArgs &a, hipStream_t s) {
   const bool wide = a.CoP % 64 == 0, deep = a.Ci % 64 == 0;
+  // the 16x16x32 path wherever a launch has more than one workgroup per CU
+  const bool mma16 = taps == 9 && wide && (i64)a.N * a.tilesX * ((a.Ho + 15) / 16) * (a.CoP / 64) > 256;
+  if (mma16) return a.bz ? launch_conv<9, 64, true, 32, 1>(a, s) : launch_conv<9, 64, false, 32, 1>(a, s);
   if (a.bz) {
     if (taps == 9) return wide ? launch_conv<9, 64, true>(a, s) : launch_conv<9, 32, true>(a, s);
     if (wide) return deep ? launch_conv<1, 64, true, 64>(a, s) : launch_conv<1, 64, true>(a, s);
