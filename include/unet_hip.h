@@ -306,6 +306,12 @@ int unet_conv3x3_bf16(const uint16_t *in, int in_ld, const uint16_t *w_packed, c
                       uint16_t *out, int out_ld, float *stat_partials, int N, int H, int W, int CiP, int CoP,
                       int accumulate, unet_stream_t stream);
 int unet_conv3x3_stat_tiles(int H, int W);
+/* Inference: the same convolution with the batch norm (running statistics) and ReLU that follow it folded into the
+ * epilogue (cudaConvolve + cudaBatchNormInference + cudaRelu in one kernel): out = relu(a*(conv + bias) + b) with
+ * {a, b} from the per-channel records of unet_bn_inference_coef_bf16; the pre-BN tensor is never written. */
+int unet_conv3x3_bn_relu_bf16(const uint16_t *in, int in_ld, const uint16_t *w_packed, const float *bias, int co_valid,
+                              const float *bn_coef, uint16_t *out, int out_ld, int N, int H, int W, int CiP, int CoP,
+                              unet_stream_t stream);
 
 /* The segmentation head: 3x3 / pad 1 / stride 1 convolution with ONE output channel (the last CONV_LAYER of
  * main.py:187-224; replaces cudaConvolve / cudaConvolveBackward, cuda_lib.h:44-256, for that layer).  The
@@ -353,6 +359,11 @@ int unet_conv3x3_wgrad_bf16(const uint16_t *dz, int dz_ld, const uint16_t *x, in
 int unet_tconv2x2_bf16(const uint16_t *in, int in_ld, const uint16_t *w_packed, const float *bias, int co_valid,
                        uint16_t *out, int out_ld, float *stat_partials, int N, int H_in, int W_in, int CiP, int CoP,
                        unet_stream_t stream);
+/* Inference: the transposed convolution with its batch norm (running statistics) and ReLU folded in, as
+ * unet_conv3x3_bn_relu_bf16. */
+int unet_tconv2x2_bn_relu_bf16(const uint16_t *in, int in_ld, const uint16_t *w_packed, const float *bias, int co_valid,
+                               const float *bn_coef, uint16_t *out, int out_ld, int N, int H_in, int W_in, int CiP,
+                               int CoP, unet_stream_t stream);
 int unet_tconv2x2_dgrad_bf16(const uint16_t *dy, int dy_ld, const uint16_t *w_packed_bwd, uint16_t *dx, int dx_ld,
                              int N, int H_in, int W_in, int CiP, int CoP, int accumulate, unet_stream_t stream);
 /* unet_tconv2x2_dgrad_bf16 (accumulate = 0) with the same fused BN-backward

@@ -496,3 +496,42 @@ def test_first_layer_with_8_stored_channels(G, capi, oracle):
         capi.unet_conv3x3_wgrad_bf16(G.p(dyt), co, G.p(xt), cp, G.p(gw), n, h, w, cp, co, ci, co, None)
         gws.append(G.host(gw))
     np.testing.assert_array_equal(gws[0], gws[1])
+
+
+@pytest.mark.parametrize("kind", ["conv", "tconv"])
+def test_inference_bn_relu_folded_into_the_epilogue(G, capi, oracle, kind):
+    """Inference: conv / transposed conv with BN (running statistics) + ReLU folded in, against the oracle's
+    convolution -> bn_inference -> relu, and against the unfused pair of entry points."""
+    n, ci, co, h, w = 2, 64, 96, 20, 24
+    cip, cop = pad32(ci), pad32(co)
+    k = 3 if kind == "conv" else 2
+    rng = np.random.default_rng(31)
+    x = bf16_round(rng.standard_normal((n, ci, h, w)))
+    wt = bf16_round(rng.standard_normal(ci * co * k * k) * (1.0 / np.sqrt(k * k * ci)))
+    bias = (rng.standard_normal(co) * 0.5).astype(np.float32)
+    gb = np.stack([rng.random(co) + 0.5, rng.standard_normal(co) * 0.3], axis=1).astype(np.float32).reshape(-1)
+    run = np.stack([rng.standard_normal(co) * 0.2, rng.random(co) + 0.5], axis=1).astype(np.float32).reshape(-1)
+    w_and_b = np.concatenate([wt, bias]).astype(np.float32)
+    xt = to_nhwc(G, capi, x)
+    fwd, _ = pack(G, capi, wt, ci, co, k)
+    bd, gbd, rund = G.dev(bias), G.dev(gb), G.dev(run)
+    coef = G.empty((cop * 4,))
+    capi.unet_bn_inference_coef_bf16(G.p(gbd), G.p(rund), co, cop, G.p(coef), None)
+    ho, wo = (h, w) if kind == "conv" else (2 * h, 2 * w)
+    y_fused = torch.full((n, ho, wo, cop), float("nan"), dtype=torch.bfloat16, device=G.DEV)
+    z = torch.zeros((n, ho, wo, cop), dtype=torch.bfloat16, device=G.DEV)
+    y_plain = torch.zeros_like(z)
+    if kind == "conv":
+        capi.unet_conv3x3_bn_relu_bf16(G.p(xt), cip, G.p(fwd), G.p(bd), co, G.p(coef), G.p(y_fused), cop, n, h, w, cip, cop, None)
+        capi.unet_conv3x3_bf16(G.p(xt), cip, G.p(fwd), G.p(bd), co, G.p(z), cop, None, n, h, w, cip, cop, 0, None)
+        z_ref = oracle.convolve(x, w_and_b, co, 3, 1, 1)
+    else:
+        capi.unet_tconv2x2_bn_relu_bf16(G.p(xt), cip, G.p(fwd), G.p(bd), co, G.p(coef), G.p(y_fused), cop, n, h, w, cip, cop, None)
+        capi.unet_tconv2x2_bf16(G.p(xt), cip, G.p(fwd), G.p(bd), co, G.p(z), cop, None, n, h, w, cip, cop, None)
+        z_ref = oracle.upsample(x, w_and_b, co, 2)
+    capi.unet_bn_act_bf16(G.p(z), cop, G.p(y_plain), cop, G.p(coef), cop, n * ho * wo, 0, None)
+    y_ref = oracle.relu(oracle.bn_inference(z_ref, gb, run))
+    got = from_nhwc(G, capi, y_fused, co)
+    assert_close_bf16(got, y_ref, what=f"{kind} + BN + ReLU folded")
+    assert_close_bf16(got, from_nhwc(G, capi, y_plain, co), what=f"{kind}: folded vs unfused")
+    assert np.all(y_fused.float().cpu().numpy()[..., co:] == 0), "padded channels must stay zero"

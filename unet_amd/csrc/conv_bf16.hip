@@ -57,6 +57,8 @@ struct ConvArgs {
   const bf16_t *bz;
   int bz_ld;
   const float4 *bcf;
+  const float4 *affine;  // forward only, or null: per-channel records {a, b, .., ..}; the epilogue then writes
+                         // relu(a * (conv + bias) + b) -- inference-time batch norm + ReLU folded into the conv
   int in_c;     // > 0: input channels present in memory (multiple of 8, < 32, single K chunk); pieces beyond
                 // it are taken as zero without touching memory (first layer: 3 image channels stored as 8)
   int bred_c0;  // output channels below this one take no part (the other half of a concat's gradient);
@@ -71,8 +73,11 @@ struct ConvArgs {
 // over dense 64-byte LDS rows whose 16-byte pieces are XOR-swizzled by (row >> 1) & 3, which makes every
 // fragment read conflict-free and the staging buffers 20 % smaller; the chip also holds a higher clock on
 // this MFMA shape.  3-5 % faster on every layer shape but the 16x16-pixel images (one workgroup per CU).
-template <int TAPS, int BN, bool BRED, int KC, int MMA = 0>
+// AFF: forward-only variant that folds inference-time batch norm + ReLU into the epilogue (a.affine); a
+// template parameter so that the training kernels carry none of it.
+template <int TAPS, int BN, bool BRED, int KC, int MMA = 0, bool AFF = false>
 __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
+  static_assert(!(AFF && BRED), "the folded BN + ReLU epilogue is a forward variant");
   static_assert(MMA == 0 || (TAPS == 9 && KC == 32), "the 16x16x32 path is written for the 3x3 kernels");
   constexpr int PITCH = MMA ? 64 : KC * 2 + 16;  // bytes per LDS row of KC bf16 (MMA 0: + 16-byte pad)
   constexpr int PPR = KC / 8;         // 16-byte pieces per row
@@ -196,7 +201,18 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
   // read back as broadcast 16-byte pieces in the epilogue
   constexpr int MAIN_BYTES = W_BYTES + NPIX * PITCH, EPI_BYTES = 256 * (BN * 2 + 16) + 2048;
   float *ldsB = reinterpret_cast<float *>(lds + (MAIN_BYTES > EPI_BYTES ? MAIN_BYTES : EPI_BYTES));
-  if (!BRED && tid < BN) ldsB[tid] = (a.bias && co0 + tid < a.co_valid) ? a.bias[co0 + tid] : 0.f;
+  float *ldsS = ldsB + BN;  // per-channel scale when a.affine (ldsB then holds the folded shift)
+  if (!BRED && tid < BN) {
+    const float bias = (a.bias && co0 + tid < a.co_valid) ? a.bias[co0 + tid] : 0.f;
+    if (AFF) {
+      const float4 cf = a.affine[co0 + tid];
+      ldsS[tid] = cf.x;
+      ldsB[tid] = fmaf(cf.x, bias, cf.y);
+    } else {
+      ldsB[tid] = bias;
+    }
+  }
+  constexpr bool affine = AFF;
 
   const int nk = (TAPS == 1) ? nk1 * a.k_phases : nk1;
   load_chunk(0);
@@ -277,7 +293,12 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
       for (int q = 0; q < 4; ++q) {
         const int pix = (wave * 4 + q) * 16 + l15, ch = m * 16 + 4 * kp;
         f32x4 v = acc4[MMA ? m : 0][MMA ? q : 0];
-        if (!BRED) v += *reinterpret_cast<const f32x4 *>(ldsB + ch);
+        if (affine) {
+          v = v * *reinterpret_cast<const f32x4 *>(ldsS + ch) + *reinterpret_cast<const f32x4 *>(ldsB + ch);
+          v = __builtin_elementwise_max(v, f32x4{0.f, 0.f, 0.f, 0.f});
+        } else if (!BRED) {
+          v += *reinterpret_cast<const f32x4 *>(ldsB + ch);
+        }
         *reinterpret_cast<bf16x4 *>(stage + pix * OP + ch * 2) = __builtin_convertvector(v, bf16x4);
       }
   } else {
@@ -290,7 +311,12 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
         for (int g = 0; g < 4; ++g) {
           const int ch = m * 32 + 8 * g + 4 * (lane >> 5);
           f32x4 v = {acc[m][q][4 * g], acc[m][q][4 * g + 1], acc[m][q][4 * g + 2], acc[m][q][4 * g + 3]};
-          if (!BRED) v += *reinterpret_cast<const f32x4 *>(ldsB + ch);
+          if (affine) {
+            v = v * *reinterpret_cast<const f32x4 *>(ldsS + ch) + *reinterpret_cast<const f32x4 *>(ldsB + ch);
+            v = __builtin_elementwise_max(v, f32x4{0.f, 0.f, 0.f, 0.f});
+          } else if (!BRED) {
+            v += *reinterpret_cast<const f32x4 *>(ldsB + ch);
+          }
           const bf16x4 h = __builtin_convertvector(v, bf16x4);
           *reinterpret_cast<bf16x4 *>(stage + pix * OP + ch * 2) = h;
         }
@@ -385,24 +411,24 @@ constexpr size_t conv_lds_bytes() {
   constexpr int PITCH = MMA ? 64 : KC * 2 + 16;
   constexpr size_t main_loop = (size_t)TAPS * BN * PITCH + (size_t)HALO * HALO * PITCH;
   constexpr size_t epilogue = (size_t)256 * (BN * 2 + 16) + 2048;
-  return (main_loop > epilogue ? main_loop : epilogue) + BN * sizeof(float);  // + the bias vector
+  return (main_loop > epilogue ? main_loop : epilogue) + 2 * BN * sizeof(float);  // + bias and scale vectors
 }
 
-template <int TAPS, int BN, bool BRED, int KC = 32, int MMA = 0>
+template <int TAPS, int BN, bool BRED, int KC = 32, int MMA = 0, bool AFF = false>
 int launch_conv(const ConvArgs &a, hipStream_t s) {
   static bool attr_set[64] = {};
   constexpr size_t lds = conv_lds_bytes<TAPS, BN, KC, MMA>();
   int dev = 0;
   UNET_HIP_TRY(hipGetDevice(&dev));
   if (!attr_set[dev & 63]) {
-    UNET_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_mfma_kernel<TAPS, BN, BRED, KC, MMA>),
+    UNET_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_mfma_kernel<TAPS, BN, BRED, KC, MMA, AFF>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set[dev & 63] = true;
   }
   const int tilesY = (a.Ho + 15) / 16;
   dim3 grid((unsigned)(tilesY * a.tilesX), (unsigned)(a.CoP / BN * (a.out_phases > 1 ? a.out_phases : 1)),
             (unsigned)a.N);
-  hipLaunchKernelGGL((conv_mfma_kernel<TAPS, BN, BRED, KC, MMA>), grid, dim3(256), lds, s, a);
+  hipLaunchKernelGGL((conv_mfma_kernel<TAPS, BN, BRED, KC, MMA, AFF>), grid, dim3(256), lds, s, a);
   UNET_LAUNCH_CHECK("conv_mfma_kernel");
   return UNET_OK;
 }
@@ -411,6 +437,12 @@ int launch_conv_any(int taps, const ConvArgs &a, hipStream_t s) {
   const bool wide = a.CoP % 64 == 0, deep = a.Ci % 64 == 0;
   // the 16x16x32 path wherever a launch has more than one workgroup per CU
   const bool mma16 = taps == 9 && wide && (i64)a.N * a.tilesX * ((a.Ho + 15) / 16) * (a.CoP / 64) > 256;
+  if (a.affine) {  // inference forward
+    if (mma16) return launch_conv<9, 64, false, 32, 1, true>(a, s);
+    if (taps == 9) return wide ? launch_conv<9, 64, false, 32, 0, true>(a, s) : launch_conv<9, 32, false, 32, 0, true>(a, s);
+    if (wide) return deep ? launch_conv<1, 64, false, 64, 0, true>(a, s) : launch_conv<1, 64, false, 32, 0, true>(a, s);
+    return launch_conv<1, 32, false, 32, 0, true>(a, s);
+  }
   if (mma16) return a.bz ? launch_conv<9, 64, true, 32, 1>(a, s) : launch_conv<9, 64, false, 32, 1>(a, s);
   if (a.bz) {
     if (taps == 9) return wide ? launch_conv<9, 64, true>(a, s) : launch_conv<9, 32, true>(a, s);
@@ -621,9 +653,9 @@ int unet_nhwc_bf16_to_nchw_f32(const uint16_t *in, float *out, int N, int C, int
   return UNET_OK;
 }
 
-int unet_conv3x3_bf16(const uint16_t *in, int in_ld, const uint16_t *w_packed, const float *bias, int co_valid,
-                      uint16_t *out, int out_ld, float *stat_partials, int N, int H, int W, int CiP, int CoP,
-                      int accumulate, unet_stream_t s) {
+static int conv3x3_impl(const uint16_t *in, int in_ld, const uint16_t *w_packed, const float *bias, int co_valid,
+                        uint16_t *out, int out_ld, float *stat_partials, int N, int H, int W, int CiP, int CoP,
+                        int accumulate, const float4 *affine, unet_stream_t s) {
   UNET_REQUIRE(in && w_packed && out, "unet_conv3x3_bf16: NULL pointer");
   UNET_REQUIRE(N > 0 && N <= 65535 && H > 0 && W > 0, "unet_conv3x3_bf16: bad sizes");
   UNET_REQUIRE(CiP > 0 && (CiP % 32 == 0 || (CiP < 32 && CiP % 8 == 0)) && CoP > 0 && CoP % 32 == 0 && in_ld >= CiP &&
@@ -645,10 +677,27 @@ int unet_conv3x3_bf16(const uint16_t *in, int in_ld, const uint16_t *w_packed, c
   a.co_valid = co_valid;
   a.out_phases = a.k_phases = 1;
   a.in_c = in_present;
+  a.affine = affine;
   const double flops = 2.0 * N * H * W * (double)CiP * CoP * 9;
   ProfScope prof(stat_partials || bias ? PROF_CONV_FWD_BF16 : PROF_CONV_DGRAD_BF16, flops,
                  2.0 * N * H * W * ((double)CiP + CoP), as_stream(s));
   return launch_conv_any(9, a, as_stream(s));
+}
+
+int unet_conv3x3_bf16(const uint16_t *in, int in_ld, const uint16_t *w_packed, const float *bias, int co_valid,
+                      uint16_t *out, int out_ld, float *stat_partials, int N, int H, int W, int CiP, int CoP,
+                      int accumulate, unet_stream_t s) {
+  return conv3x3_impl(in, in_ld, w_packed, bias, co_valid, out, out_ld, stat_partials, N, H, W, CiP, CoP, accumulate,
+                      nullptr, s);
+}
+
+int unet_conv3x3_bn_relu_bf16(const uint16_t *in, int in_ld, const uint16_t *w_packed, const float *bias, int co_valid,
+                              const float *bn_coef, uint16_t *out, int out_ld, int N, int H, int W, int CiP, int CoP,
+                              unet_stream_t s) {
+  UNET_REQUIRE(bn_coef && (((uintptr_t)bn_coef) & 15) == 0,
+               "unet_conv3x3_bn_relu_bf16: bn_coef must be a 16-byte aligned pointer");
+  return conv3x3_impl(in, in_ld, w_packed, bias, co_valid, out, out_ld, nullptr, N, H, W, CiP, CoP, 0,
+                      reinterpret_cast<const float4 *>(bn_coef), s);
 }
 
 int unet_conv3x3_stat_tiles(int H, int W) { return ((H + 15) / 16) * ((W + 15) / 16); }
@@ -685,9 +734,9 @@ int unet_conv3x3_dgrad_bnred_bf16(const uint16_t *dz, int dz_ld, const uint16_t 
 
 // One (i,j) phase launch per call is an implementation detail: these entry
 // points run all four phases of the 2x2 stride-2 transposed convolution.
-int unet_tconv2x2_bf16(const uint16_t *in, int in_ld, const uint16_t *w_packed, const float *bias, int co_valid,
-                       uint16_t *out, int out_ld, float *stat_partials, int N, int H_in, int W_in, int CiP, int CoP,
-                       unet_stream_t s) {
+static int tconv2x2_impl(const uint16_t *in, int in_ld, const uint16_t *w_packed, const float *bias, int co_valid,
+                         uint16_t *out, int out_ld, float *stat_partials, int N, int H_in, int W_in, int CiP, int CoP,
+                         const float4 *affine, unet_stream_t s) {
   UNET_REQUIRE(in && w_packed && out, "unet_tconv2x2_bf16: NULL pointer");
   UNET_REQUIRE(N > 0 && N <= 65535 && H_in > 0 && W_in > 0, "unet_tconv2x2_bf16: bad sizes");
   UNET_REQUIRE(CiP > 0 && CiP % 32 == 0 && CoP > 0 && CoP % 32 == 0 && in_ld >= CiP && out_ld >= CoP &&
@@ -708,7 +757,23 @@ int unet_tconv2x2_bf16(const uint16_t *in, int in_ld, const uint16_t *w_packed, 
   a.out_phases = 4; a.k_phases = 1;
   a.wt_phase_stride = (i64)CoP * CiP;
   a.stats_phase_stride = (i64)N * tiles * CoP * 2;
+  a.affine = affine;
   return launch_conv_any(1, a, as_stream(s));
+}
+
+int unet_tconv2x2_bf16(const uint16_t *in, int in_ld, const uint16_t *w_packed, const float *bias, int co_valid,
+                       uint16_t *out, int out_ld, float *stat_partials, int N, int H_in, int W_in, int CiP, int CoP,
+                       unet_stream_t s) {
+  return tconv2x2_impl(in, in_ld, w_packed, bias, co_valid, out, out_ld, stat_partials, N, H_in, W_in, CiP, CoP, nullptr, s);
+}
+
+int unet_tconv2x2_bn_relu_bf16(const uint16_t *in, int in_ld, const uint16_t *w_packed, const float *bias, int co_valid,
+                               const float *bn_coef, uint16_t *out, int out_ld, int N, int H_in, int W_in, int CiP,
+                               int CoP, unet_stream_t s) {
+  UNET_REQUIRE(bn_coef && (((uintptr_t)bn_coef) & 15) == 0,
+               "unet_tconv2x2_bn_relu_bf16: bn_coef must be a 16-byte aligned pointer");
+  return tconv2x2_impl(in, in_ld, w_packed, bias, co_valid, out, out_ld, nullptr, N, H_in, W_in, CiP, CoP,
+                       reinterpret_cast<const float4 *>(bn_coef), s);
 }
 
 // dX[n,h,w,ci] = sum_{i,j} sum_co dY[n,2h+i,2w+j,co] * W[ci,co,i,j];  w_packed_bwd = [phase][CiP][CoP]

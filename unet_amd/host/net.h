@@ -986,6 +986,18 @@ class Net {
         const float *gb = w + n.num_wb;
         float *parts = (inference || n.narrow) ? nullptr : n.stat_partials.f32();
         int num_parts;
+        const bool fold_bn = inference && !n.narrow && !(n.type == CONV_LAYER && n.activation == SIGMOID);
+        if (fold_bn) {
+          // inference: BN (running statistics) + ReLU folded into the conv epilogue, straight into y
+          UNET_CALL(unet_bn_inference_coef_bf16(gb, n.running.f32(), n.out_c, n.cop, n.coef.f32(), stream_));
+          if (n.type == CONV_LAYER)
+            UNET_CALL(unet_conv3x3_bn_relu_bf16(in, in_ld, n.w_fwd.u16(), bias, n.out_c, n.coef.f32(), n.y_ptr, n.y_ld, batch,
+                                                n.in_h, n.in_w, in_cip, n.cop, stream_));
+          else
+            UNET_CALL(unet_tconv2x2_bn_relu_bf16(in, in_ld, n.w_fwd.u16(), bias, n.out_c, n.coef.f32(), n.y_ptr, n.y_ld, batch,
+                                                 n.in_h, n.in_w, n.cip, n.cop, stream_));
+          break;
+        }
         if (n.head) {
           UNET_CALL(unet_conv3x3_head_bf16(in, in_ld, n.w_fwd.u16(), bias, n.z.f32(), batch, n.in_h, n.in_w, n.cip, n.cop,
                                            stream_));
