@@ -220,25 +220,33 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
   __syncthreads();
   for (int kc = 0; kc < nk; ++kc) {
     if (kc + 1 < nk) load_chunk(kc + 1);
+    if (MMA) {
+      // Per filter column kw the wave needs 6 halo rows (its 4 pixel rows + 2): each is read once and serves
+      // the up to three (kh, q) pairs with q + kh = row -- 18 pixel fragments per chunk instead of 36.
 #pragma unroll
-    for (int tap = 0; tap < TAPS; ++tap) {
-      const int kh = (TAPS == 9) ? tap / 3 : 0, kw = (TAPS == 9) ? tap % 3 : 0;
-      if (MMA) {
-        bf16x8 af[MB], bfr[4];
+      for (int kw = 0; kw < 3; ++kw) {
+        bf16x8 brow[6];
 #pragma unroll
-        for (int m = 0; m < MB; ++m)
-          af[m] = *reinterpret_cast<const bf16x8 *>(ldsW + (tap * BN + m * 16) * 64 + a4_lane);
+        for (int r = 0; r < 6; ++r)
+          brow[r] = *reinterpret_cast<const bf16x8 *>(ldsX + r * HALO * 64 + b4_off[MMA ? kw : 0][MMA ? (r & 3) : 0]);
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-          bfr[q] = *reinterpret_cast<const bf16x8 *>(ldsX + (q + kh) * HALO * 64 + b4_off[MMA ? kw : 0][MMA ? ((q + kh) & 3) : 0]);
+        for (int kh = 0; kh < 3; ++kh) {
+          bf16x8 af[MB];
 #pragma unroll
-        for (int m = 0; m < MB; ++m)
+          for (int m = 0; m < MB; ++m)
+            af[m] = *reinterpret_cast<const bf16x8 *>(ldsW + ((kh * 3 + kw) * BN + m * 16) * 64 + a4_lane);
 #pragma unroll
-          for (int q = 0; q < 4; ++q)
-            acc4[MMA ? m : 0][MMA ? q : 0] =
-                __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[m], bfr[q], acc4[MMA ? m : 0][MMA ? q : 0], 0, 0, 0);
-        continue;
+          for (int m = 0; m < MB; ++m)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              acc4[MMA ? m : 0][MMA ? q : 0] =
+                  __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[m], brow[q + kh], acc4[MMA ? m : 0][MMA ? q : 0], 0, 0, 0);
+        }
       }
+    }
+#pragma unroll
+    for (int tap = 0; tap < (MMA ? 0 : TAPS); ++tap) {
+      const int kh = (TAPS == 9) ? tap / 3 : 0, kw = (TAPS == 9) ? tap % 3 : 0;
 #pragma unroll
       for (int ks = 0; ks < KC / 16; ++ks) {
         bf16x8 af[MF], bfr[2];
@@ -435,8 +443,10 @@ int launch_conv(const ConvArgs &a, hipStream_t s) {
 
 int launch_conv_any(int taps, const ConvArgs &a, hipStream_t s) {
   const bool wide = a.CoP % 64 == 0, deep = a.Ci % 64 == 0;
-  // the 16x16x32 path wherever a launch has more than one workgroup per CU
-  const bool mma16 = taps == 9 && wide && (i64)a.N * a.tilesX * ((a.Ho + 15) / 16) * (a.CoP / 64) > 256;
+  // the 16x16x32 path for all but the smallest images (at batch 16: wherever a launch has more than one workgroup
+  // per CU).  The choice must not depend on the batch size: the two loops add in different orders, and inference
+  // on one image has to give bit for bit what the same image gives inside a batch.
+  const bool mma16 = taps == 9 && wide && (i64)a.tilesX * ((a.Ho + 15) / 16) * (a.CoP / 64) > 16;
   if (a.affine) {  // inference forward
     if (mma16) return launch_conv<9, 64, false, 32, 1, true>(a, s);
     if (taps == 9) return wide ? launch_conv<9, 64, false, 32, 0, true>(a, s) : launch_conv<9, 32, false, 32, 0, true>(a, s);
