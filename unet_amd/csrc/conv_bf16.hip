@@ -167,7 +167,11 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
 
   constexpr int MB = BN / 16;  // MMA 1: 16-channel blocks
   f32x16 acc[MMA ? 1 : MF][MMA ? 1 : 2];  // MMA 0: [32-channel block][32-pixel block]
-  f32x4 acc4[MMA ? MB : 1][MMA ? 4 : 1];  // MMA 1: [16-channel block][pixel row of the wave]
+  // MMA 1: wave = (pixel half ph: tile rows 8ph..8ph+7, channel half cw: 16-channel blocks 2cw, 2cw+1);
+  // acc4[16-channel block of the wave][pixel row of the wave].  A 2 x 2 split reads 18 weight + 30 pixel
+  // fragments per chunk where 1 x 4 (every wave all channels) read 36 + 18.
+  constexpr int MW = MB / 2, QW = 8;
+  f32x4 acc4[MMA ? MW : 1][MMA ? QW : 1];
 #pragma unroll
   for (int m = 0; m < (MMA ? 1 : MF); ++m)
 #pragma unroll
@@ -175,9 +179,10 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[m][q][r] = 0.f;
 #pragma unroll
-  for (int m = 0; m < (MMA ? MB : 1); ++m)
+  for (int m = 0; m < (MMA ? MW : 1); ++m)
 #pragma unroll
-    for (int q = 0; q < (MMA ? 4 : 1); ++q) acc4[m][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int q = 0; q < (MMA ? QW : 1); ++q) acc4[m][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int ph = wave & 1, cw = wave >> 1;
 
   const int a_lane = (lane & 31) * PITCH + (lane >> 5) * 16;
   const int b_lane = ((wave * 4 + ((lane & 31) >> 4)) * HALO + (lane & 15)) * PITCH + (lane >> 5) * 16;
@@ -193,7 +198,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
 #pragma unroll
       for (int rc = 0; rc < 4; ++rc) {
         const int pl = rc * HALO + l15 + kw;
-        b4_off[MMA ? kw : 0][MMA ? rc : 0] = (l15 + kw) * 64 + ((kp ^ ((pl >> 1) & 3)) * 16) + wave * 4 * HALO * 64;
+        b4_off[MMA ? kw : 0][MMA ? rc : 0] = (l15 + kw) * 64 + ((kp ^ ((pl >> 1) & 3)) * 16) + ph * 8 * HALO * 64;
       }
   }
 
@@ -221,24 +226,24 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
   for (int kc = 0; kc < nk; ++kc) {
     if (kc + 1 < nk) load_chunk(kc + 1);
     if (MMA) {
-      // Per filter column kw the wave needs 6 halo rows (its 4 pixel rows + 2): each is read once and serves
-      // the up to three (kh, q) pairs with q + kh = row -- 18 pixel fragments per chunk instead of 36.
+      // Per filter column kw the wave needs 10 halo rows (its 8 pixel rows + 2): each is read once and serves
+      // the up to three (kh, q) pairs with q + kh = row.
 #pragma unroll
       for (int kw = 0; kw < 3; ++kw) {
-        bf16x8 brow[6];
+        bf16x8 brow[QW + 2];
 #pragma unroll
-        for (int r = 0; r < 6; ++r)
+        for (int r = 0; r < QW + 2; ++r)
           brow[r] = *reinterpret_cast<const bf16x8 *>(ldsX + r * HALO * 64 + b4_off[MMA ? kw : 0][MMA ? (r & 3) : 0]);
 #pragma unroll
         for (int kh = 0; kh < 3; ++kh) {
-          bf16x8 af[MB];
+          bf16x8 af[MW];
 #pragma unroll
-          for (int m = 0; m < MB; ++m)
-            af[m] = *reinterpret_cast<const bf16x8 *>(ldsW + ((kh * 3 + kw) * BN + m * 16) * 64 + a4_lane);
+          for (int m = 0; m < MW; ++m)
+            af[m] = *reinterpret_cast<const bf16x8 *>(ldsW + ((kh * 3 + kw) * BN + (cw * MW + m) * 16) * 64 + a4_lane);
 #pragma unroll
-          for (int m = 0; m < MB; ++m)
+          for (int m = 0; m < MW; ++m)
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
+            for (int q = 0; q < QW; ++q)
               acc4[MMA ? m : 0][MMA ? q : 0] =
                   __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[m], brow[q + kh], acc4[MMA ? m : 0][MMA ? q : 0], 0, 0, 0);
         }
@@ -296,10 +301,10 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
   }
   if (MMA) {
 #pragma unroll
-    for (int m = 0; m < MB; ++m)
+    for (int m = 0; m < MW; ++m)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int pix = (wave * 4 + q) * 16 + l15, ch = m * 16 + 4 * kp;
+      for (int q = 0; q < QW; ++q) {
+        const int pix = (ph * QW + q) * 16 + l15, ch = (cw * MW + m) * 16 + 4 * kp;
         f32x4 v = acc4[MMA ? m : 0][MMA ? q : 0];
         if (affine) {
           v = v * *reinterpret_cast<const f32x4 *>(ldsS + ch) + *reinterpret_cast<const f32x4 *>(ldsB + ch);
