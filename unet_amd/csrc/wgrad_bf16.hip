@@ -134,16 +134,41 @@ __global__ __launch_bounds__(256, 1) void wgrad_mfma_kernel(const WgradArgs a) {
   __syncthreads();
   for (int chunk = c_begin; chunk < c_end; ++chunk) {
     if (chunk + 1 < c_end) load_chunk(chunk + 1);
+    if (TAPS == 9) {
+      // Walk the 10 halo rows of the chunk: the x fragment of (row r, filter column kw) is read once and
+      // multiplies the dz fragments of pixel rows r, r-1, r-2 (filter rows 0, 1, 2) -- 30 + 8 fragment
+      // reads per chunk instead of 72 + 8.  Each accumulator still sums its pixel rows in ascending order.
+      bf16x8 aw[3];
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
-      const unsigned char *zp = ldsZ + ks * 16 * WP + z_lane;
-      const bf16x8 af = tr_read_pair(zp, zp + 4 * WP);
+      for (int r = 0; r < 10; ++r) {
+        if (r < 8) {
+          const unsigned char *zp = ldsZ + r * 16 * WP + z_lane;
+          aw[r % 3] = tr_read_pair(zp, zp + 4 * WP);
+        }
 #pragma unroll
-      for (int t = 0; t < TAPS; ++t) {
-        const int kh = (TAPS == 9) ? t / 3 : 0, kw = (TAPS == 9) ? t % 3 : 0;
-        const unsigned char *xp = ldsX + ((ks + kh) * XC + kw) * WP + x_lane;
-        const bf16x8 bfr = tr_read_pair(xp, xp + 4 * WP);
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, acc[t], 0, 0, 0);
+        for (int kw = 0; kw < 3; ++kw) {
+          const unsigned char *xp = ldsX + (r * XC + kw) * WP + x_lane;
+          const bf16x8 bfr = tr_read_pair(xp, xp + 4 * WP);
+#pragma unroll
+          for (int kh = 0; kh < 3; ++kh) {
+            const int ks = r - kh;
+            if (ks >= 0 && ks < 8)
+              acc[(TAPS == 9) ? kh * 3 + kw : 0] =
+                  __builtin_amdgcn_mfma_f32_32x32x16_bf16(aw[ks % 3], bfr, acc[(TAPS == 9) ? kh * 3 + kw : 0], 0, 0, 0);
+          }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        const unsigned char *zp = ldsZ + ks * 16 * WP + z_lane;
+        const bf16x8 af = tr_read_pair(zp, zp + 4 * WP);
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t) {
+          const unsigned char *xp = ldsX + ks * XC * WP + x_lane;
+          const bf16x8 bfr = tr_read_pair(xp, xp + 4 * WP);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, acc[t], 0, 0, 0);
+        }
       }
     }
     __syncthreads();
