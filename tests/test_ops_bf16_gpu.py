@@ -80,6 +80,10 @@ CONV_CASES = [
     (1, 3, 64, 33, 17),      # first-layer-like (C_in padded 3 -> 32)
     (2, 64, 1, 16, 24),      # last-layer-like (C_out padded 1 -> 32)
     (1, 128, 64, 48, 48),
+    # enough tiles x channel blocks for the 16x16x32 main loop (forward and, for the last one, data gradient too)
+    (1, 64, 128, 40, 72),    # ragged tiles, 2 K chunks, 2 channel blocks
+    (1, 32, 64, 80, 80),     # one K chunk
+    (1, 128, 64, 72, 72),    # 4 K chunks; data gradient with 2 channel blocks
 ]
 
 
@@ -291,7 +295,8 @@ def test_max_pool_bf16(G, capi, oracle, cfg):
     np.testing.assert_array_equal(nchw(dx, c), bf16_round(2 * dx_ref))
 
 
-@pytest.mark.parametrize("cfg", [("conv", 2, 64, 64, 24, 40), ("conv", 1, 32, 96, 16, 16), ("tconv", 2, 64, 32, 8, 12)])
+@pytest.mark.parametrize("cfg", [("conv", 2, 64, 64, 24, 40), ("conv", 1, 32, 96, 16, 16), ("tconv", 2, 64, 32, 8, 12),
+                                 ("conv", 1, 64, 64, 72, 80)])   # the last one runs the 16x16x32 main loop
 def test_dgrad_with_fused_bn_backward_reduction(G, capi, cfg):
     """The data-gradient kernels that also reduce the parent's batch-norm backward over the pixels:
     dx is bit-identical to the plain data gradient, and dz / dgamma / dbeta / dbias agree with the
