@@ -274,8 +274,8 @@ __global__ __launch_bounds__(256) void bn_finalize_bwd_kernel(const float *__res
   if (threadIdx.x == 0) out[c] = r;
 }
 
-// pass 2: dz = c0*(g - k1 - xhat*k2) (bf16) and per-block sums of dz (bias gradient)
-template <int ACT>
+// pass 2: dz = c0*(g - k1 - xhat*k2) (bf16) and, with BIAS, per-block sums of dz (bias gradient)
+template <int ACT, bool BIAS = true>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16_t *__restrict__ dy1, int ld1,
                                                            const bf16_t *__restrict__ dy2, int ld2,
                                                            const bf16_t *__restrict__ z, int z_ld,
@@ -316,10 +316,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16_t *__restr
         o[j] = b[j].c0 * (gj - b[j].k1 - xh * b[j].k2);
       }
       const uint4 packed = pack8(o);
-      float r[8];
-      unpack8(packed, r);  // the bias gradient sums what the weight-gradient kernels will read
+      if (BIAS) {
+        float r[8];
+        unpack8(packed, r);  // the bias gradient sums what the weight-gradient kernels will read
 #pragma unroll
-      for (int j = 0; j < 8; ++j) s[j] += r[j];
+        for (int j = 0; j < 8; ++j) s[j] += r[j];
+      }
       return packed;
     };
     const uint4 zero4 = make_uint4(0, 0, 0, 0);
@@ -342,9 +344,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16_t *__restr
           apply(*reinterpret_cast<const uint4 *>(dy1 + p * ld1 + cg * 8),
                 dy2 ? *reinterpret_cast<const uint4 *>(dy2 + p * ld2 + cg * 8) : zero4,
                 *reinterpret_cast<const uint4 *>(z + p * z_ld + cg * 8));
+    if (BIAS) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) red[(pl * CG + cg) * 8 + j] = s[j];
+      for (int j = 0; j < 8; ++j) red[(pl * CG + cg) * 8 + j] = s[j];
+    }
   }
+  if (!BIAS) return;
   __syncthreads();
   for (int t = tid; t < CG * 8; t += 256) {
     float acc = 0.f;
@@ -556,9 +561,14 @@ int unet_bn_act_backward_bf16(const uint16_t *dy1, int ld1, const uint16_t *dy2,
     UNET_LAUNCH_CHECK("bn_finalize_bwd_kernel");                                                                    \
     {                                                                                                               \
       ProfScope prof(PROF_BN_BWD_APPLY_BF16, 0, 2.0 * elems * (dy2 ? 4.0 : 3.0), as_stream(s));                     \
-      hipLaunchKernelGGL(bn_bwd_apply_kernel<ACT_>, dim3(pl.blocks), dim3(256), lds2, as_stream(s), dy1, ld1,      \
-                         dy2, ld2, z, z_ld, cf, (const ChanBwd *)cb, dz, dz_ld, pl.CG, pl.PL, (i64)pixels, pl.ppb,  \
-                         bias_part, CoP);                                                                           \
+      if (grad_bias)                                                                                               \
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<ACT_, true>), dim3(pl.blocks), dim3(256), lds2, as_stream(s), dy1,  \
+                           ld1, dy2, ld2, z, z_ld, cf, (const ChanBwd *)cb, dz, dz_ld, pl.CG, pl.PL, (i64)pixels,  \
+                           pl.ppb, bias_part, CoP);                                                                 \
+      else                                                                                                          \
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<ACT_, false>), dim3(pl.blocks), dim3(256), 0, as_stream(s), dy1,    \
+                           ld1, dy2, ld2, z, z_ld, cf, (const ChanBwd *)cb, dz, dz_ld, pl.CG, pl.PL, (i64)pixels,  \
+                           pl.ppb, (float *)nullptr, CoP);                                                          \
     }                                                                                                               \
     UNET_LAUNCH_CHECK("bn_bwd_apply_kernel");                                                                       \
   } while (0)
@@ -600,9 +610,14 @@ int unet_bn_act_backward_from_partials_bf16(const uint16_t *dy, int dy_ld, const
   UNET_LAUNCH_CHECK("bn_finalize_bwd_kernel");
   {
     ProfScope prof(PROF_BN_BWD_APPLY_BF16, 0, 2.0 * (double)pixels * CoP * 3.0, as_stream(s));
-    hipLaunchKernelGGL(bn_bwd_apply_kernel<0>, dim3(pl.blocks), dim3(256), sizeof(float) * (size_t)pl.PL * pl.CG * 8,
-                       as_stream(s), dy, dy_ld, (const bf16_t *)nullptr, 0, z, z_ld, cf, (const ChanBwd *)cb, dz, dz_ld,
-                       pl.CG, pl.PL, (i64)pixels, pl.ppb, bias_part, CoP);
+    if (grad_bias)
+      hipLaunchKernelGGL((bn_bwd_apply_kernel<0, true>), dim3(pl.blocks), dim3(256),
+                         sizeof(float) * (size_t)pl.PL * pl.CG * 8, as_stream(s), dy, dy_ld, (const bf16_t *)nullptr, 0, z,
+                         z_ld, cf, (const ChanBwd *)cb, dz, dz_ld, pl.CG, pl.PL, (i64)pixels, pl.ppb, bias_part, CoP);
+    else
+      hipLaunchKernelGGL((bn_bwd_apply_kernel<0, false>), dim3(pl.blocks), dim3(256), 0, as_stream(s), dy, dy_ld,
+                         (const bf16_t *)nullptr, 0, z, z_ld, cf, (const ChanBwd *)cb, dz, dz_ld, pl.CG, pl.PL,
+                         (i64)pixels, pl.ppb, (float *)nullptr, CoP);
   }
   UNET_LAUNCH_CHECK("bn_bwd_apply_kernel");
   if (grad_bias) {

@@ -199,6 +199,7 @@ class Net {
     }
     params_.ensure(sizeof(float) * (size_t)std::max<int64_t>(total_params_, 1));
     grads_.ensure(sizeof(float) * (size_t)std::max<int64_t>(total_params_, 1));
+    UNET_CALL(unet_memset(grads_.raw(), 0, sizeof(float) * (size_t)std::max<int64_t>(total_params_, 1), stream_));
     adam_.ensure(sizeof(float) * 2 * (size_t)std::max<int64_t>(total_params_, 1));
     init_parameters(seed_);
     if (verbose_)
@@ -1058,6 +1059,14 @@ class Net {
            c.cop % 64 == 0 && u.cop == c.c2 && !(u.type == CONV_LAYER && u.activation == SIGMOID);
   }
 
+  // The gradient of a convolution bias that feeds a batch norm is identically zero: dz, the batch-norm
+  // backward output, sums to zero over the batch (sum dz = c0 * (sum g - M*k1 - k2 * sum xhat), with
+  // k1 = sum g / M and sum xhat = 0).  The reference adds up the computed dz (convolution.cu:153-414), which
+  // yields rounding noise around zero -- noise that Adam then normalises into steps of the size of the
+  // learning rate.  On the bf16 path every bias feeds a batch norm, so the engine leaves those gradient
+  // entries at the exact value (the vector is cleared once, when it is allocated) and saves a reduction per
+  // layer; the fp32 path and the op-level entry points (grad_bias != NULL) still compute the sum.
+  static constexpr float *kNoBiasGrad = nullptr;
   void backward_node_bf16(Node &n, int batch) {
     const int64_t out_pix = (int64_t)batch * n.out_h * n.out_w;
     switch (n.type) {
@@ -1106,10 +1115,13 @@ class Net {
           if (n.bwd_partials_n > 0)  // the consumer's data-gradient kernel already reduced over the pixels
             UNET_CALL(unet_bn_act_backward_from_partials_bf16(d1, l1, n.zb.u16(), n.cop, n.coef.f32(), w + n.num_wb,
                                                               n.bwd_partials.f32(), n.bwd_partials_n, dz, n.cop,
-                                                              gw + n.num_wb, gbias, n.out_c, n.cop, out_pix, stream_));
+                                                              gw + n.num_wb, kNoBiasGrad, n.out_c, n.cop, out_pix,
+                                                              stream_));
           else
             UNET_CALL(unet_bn_act_backward_bf16(d1, l1, d2, n.g2_ld, n.zb.u16(), n.cop, n.coef.f32(), w + n.num_wb, dz,
-                                                n.cop, gw + n.num_wb, gbias, n.out_c, n.cop, out_pix, act, stream_));
+                                                n.cop, gw + n.num_wb, kNoBiasGrad, n.out_c, n.cop, out_pix, act,
+                                                stream_));
+          (void)gbias;
         }
         const uint16_t *x = n.parents.empty() ? x16_.u16() : nodes_[n.parents[0]].y_ptr;
         const int x_ld = n.parents.empty() ? in_cp() : nodes_[n.parents[0]].y_ld;
