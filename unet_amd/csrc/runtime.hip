@@ -95,7 +95,9 @@ hipEvent_t prof_event() {
     return e;
   }
   hipEvent_t e = nullptr;
-  (void)hipEventCreate(&e);
+  // no system-scope release at the record: the timers bracket kernels of one stream, nothing on the host reads
+  // what those kernels wrote through these events
+  (void)hipEventCreateWithFlags(&e, hipEventDisableSystemFence);
   return e;
 }
 }  // namespace
