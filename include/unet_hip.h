@@ -419,6 +419,21 @@ int unet_max_pool2x2_bf16(const uint16_t *x, int x_ld, uint16_t *y, int y_ld, ui
                           int C, unet_stream_t stream);
 int unet_max_pool2x2_backward_bf16(const uint16_t *dy, int dy_ld, const uint8_t *mask, uint16_t *dx, int dx_ld, int N,
                                    int H, int W, int C, int accumulate, unet_stream_t stream);
+/* unet_bn_act_bf16 followed by unet_max_pool2x2_bf16 in one pass over z (the
+ * encoder's conv -> BN -> ReLU -> cudaMaxPool chain): writes the activation y,
+ * the pooled activation and the tie mask; results identical to the two calls. */
+int unet_bn_act_pool_bf16(const uint16_t *z, int z_ld, uint16_t *y, int y_ld, const float *coef, uint16_t *pooled,
+                          int pooled_ld, uint8_t *mask, int N, int H, int W, int CoP, int act, unet_stream_t stream);
+/* unet_max_pool2x2_backward_bf16 followed by unet_bn_act_backward_bf16 without
+ * the full-resolution pool gradient in between (cudaMaxPoolBackward +
+ * cudaAddBtoA + cudaReluBackward + cudaBatchNormBackward of a skip layer): the
+ * incoming gradient is dy (may be NULL) plus pooled_dy routed through the tie
+ * mask; z, dz and dy are [N][H][W] pixels, pooled_dy and mask [N][H/2][W/2].
+ * Results identical to the two calls. */
+int unet_bn_act_backward_pooled_bf16(const uint16_t *dy, int dy_ld, const uint16_t *pooled_dy, int pooled_ld,
+                                     const uint8_t *mask, int N, int H, int W, const uint16_t *z, int z_ld,
+                                     const float *coef, const float *gamma_beta, uint16_t *dz, int dz_ld,
+                                     float *grad_gb, float *grad_bias, int C, int CoP, int act, unet_stream_t stream);
 
 #ifdef __cplusplus
 }

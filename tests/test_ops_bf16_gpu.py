@@ -295,6 +295,77 @@ def test_max_pool_bf16(G, capi, oracle, cfg):
     np.testing.assert_array_equal(nchw(dx, c), bf16_round(2 * dx_ref))
 
 
+@pytest.mark.parametrize("cfg", [(2, 64, 16, 16, 0, True), (1, 32, 6, 10, 0, False), (3, 96, 8, 12, 1, True),
+                                 (2, 128, 40, 24, 0, True), (1, 8, 2, 2, 2, False)])
+def test_bn_act_with_fused_max_pool_forward_and_backward(G, capi, oracle, cfg):
+    """The skip layers' fused passes (activation + pool; pool backward gathered inside the BN backward): the
+    forward must give bit for bit what the separate calls give, the backward the same values up to the order of
+    the fp32 sums, and both the oracle's pool / BN results on the same operands."""
+    n, c, h, w, act, with_dy = cfg
+    rng = np.random.default_rng(c + 3 * h + act)
+    z = bf16_round(np.round(rng.standard_normal((n, c, h, w)) * 3) / 3 + 0.2)   # coarse values: ties in the windows
+    gb = (rng.standard_normal(2 * c) * 0.5 + np.tile([1.0, 0.0], c)).astype(np.float32)
+    M = n * h * w
+    partial = np.zeros((1, c, 2), np.float32)
+    partial[0, :, 0] = z.sum(axis=(0, 2, 3))
+    partial[0, :, 1] = (z.astype(np.float64) ** 2).sum(axis=(0, 2, 3))
+    zt, pd, gbd, rund = nhwc_tensor(G, z, c), G.dev(partial), G.dev(gb), G.dev(np.ones(2 * c, np.float32))
+    stats, coef = G.empty((2 * c,)), G.empty((capi.lib().unet_bn_coef_floats(c),))
+    capi.unet_bn_finalize_bf16(G.p(pd), 1, c, c, M, G.p(gbd), G.p(stats), G.p(rund), G.p(coef), None)
+    ld = c + 8                                                                     # y lives in a wider buffer
+    y_sep = torch.zeros((n, h, w, ld), dtype=torch.bfloat16, device=G.DEV)
+    y_fus = torch.zeros_like(y_sep)
+    p_sep = torch.empty((n, h // 2, w // 2, c), dtype=torch.bfloat16, device=G.DEV)
+    p_fus = torch.full_like(p_sep, float("nan"))
+    m_sep = torch.empty((n, h // 2, w // 2, c), dtype=torch.uint8, device=G.DEV)
+    m_fus = torch.full_like(m_sep, 255)
+    capi.unet_bn_act_bf16(G.p(zt), c, G.p(y_sep), ld, G.p(coef), c, M, act, None)
+    capi.unet_max_pool2x2_bf16(G.p(y_sep), ld, G.p(p_sep), c, G.p(m_sep), n, h, w, c, None)
+    capi.unet_bn_act_pool_bf16(G.p(zt), c, G.p(y_fus), ld, G.p(coef), G.p(p_fus), c, G.p(m_fus), n, h, w, c, act, None)
+    assert torch.equal(y_sep, y_fus) and torch.equal(p_sep, p_fus) and torch.equal(m_sep, m_fus)
+    y_host = y_fus.float().cpu().numpy()[..., :c].transpose(0, 3, 1, 2)
+    p_ref, tm_ref = oracle.maxpool(y_host, 2, 2, want_tiemask=True)
+    np.testing.assert_array_equal(nchw(p_fus, c), p_ref)
+    np.testing.assert_array_equal(m_fus.cpu().numpy().transpose(0, 3, 1, 2), tm_ref)
+
+    # backward: (optional) full-resolution gradient + the pooled gradient routed through the tie mask
+    dy = bf16_round(rng.standard_normal((n, c, h, w)))
+    dp = bf16_round(rng.standard_normal((n, c, h // 2, w // 2)))
+    dyt, dpt = nhwc_tensor(G, dy, c), nhwc_tensor(G, dp, c)
+    scattered = torch.empty((n, h, w, c), dtype=torch.bfloat16, device=G.DEV)
+    capi.unet_max_pool2x2_backward_bf16(G.p(dpt), c, G.p(m_sep), G.p(scattered), c, n, h, w, c, 0, None)
+    dz_sep = torch.empty((n, h, w, c), dtype=torch.bfloat16, device=G.DEV)
+    dz_fus = torch.full_like(dz_sep, float("nan"))
+    ggb_sep, ggb_fus, gbias_sep, gbias_fus = G.empty((2 * c,)), G.empty((2 * c,)), G.empty((c,)), G.empty((c,))
+    if with_dy:
+        capi.unet_bn_act_backward_bf16(G.p(dyt), c, G.p(scattered), c, G.p(zt), c, G.p(coef), G.p(gbd), G.p(dz_sep), c,
+                                       G.p(ggb_sep), G.p(gbias_sep), c, c, M, act, None)
+    else:
+        capi.unet_bn_act_backward_bf16(G.p(scattered), c, None, 0, G.p(zt), c, G.p(coef), G.p(gbd), G.p(dz_sep), c,
+                                       G.p(ggb_sep), G.p(gbias_sep), c, c, M, act, None)
+    capi.unet_bn_act_backward_pooled_bf16(G.p(dyt) if with_dy else None, c, G.p(dpt), c, G.p(m_fus), n, h, w, G.p(zt), c,
+                                          G.p(coef), G.p(gbd), G.p(dz_fus), c, G.p(ggb_fus), G.p(gbias_fus), c, c, act,
+                                          None)
+    # the fused passes add per pooling window, the separate ones per pixel: same sums, another order
+    assert_close(G.host(ggb_fus), G.host(ggb_sep), rtol=1e-5, atol_scale=1e-5, what="dgamma/dbeta fused vs separate")
+    assert_close_bf16(dz_fus.float().cpu().numpy(), dz_sep.float().cpu().numpy(), what="dz fused vs separate")
+    assert_close(G.host(gbias_fus), nchw(dz_fus, c).astype(np.float64).sum(axis=(0, 2, 3)), rtol=1e-4, atol_scale=1e-4,
+                 what="bias gradient = sum of dz")
+    # and against the oracle
+    bn_ref, stats_ref, _ = oracle.bn_train(z, gb, np.ones(2 * c, np.float32))
+    g_in = oracle.maxpool_backward(dp, y_host, p_ref, 2) + (dy if with_dy else 0)
+    if act == 0:
+        g = oracle.relu_backward(g_in, bn_ref)
+    elif act == 1:
+        g = oracle.sigmoid_backward(g_in, oracle.sigmoid(bn_ref))
+    else:
+        g = g_in
+    dz_ref, ggb_ref = oracle.bn_backward(z, g.astype(np.float32), gb, stats_ref)
+    assert_close_bf16(nchw(dz_fus, c), dz_ref, what=f"pooled bn+act backward {cfg}")
+    gg = G.host(ggb_fus)
+    assert np.abs(gg - ggb_ref).max() <= 2e-3 * np.abs(ggb_ref).max() + 1e-4
+
+
 @pytest.mark.parametrize("cfg", [("conv", 2, 64, 64, 24, 40), ("conv", 1, 32, 96, 16, 16), ("tconv", 2, 64, 32, 8, 12),
                                  ("conv", 1, 64, 64, 72, 80)])   # the last one runs the 16x16x32 main loop
 def test_dgrad_with_fused_bn_backward_reduction(G, capi, cfg):

@@ -358,6 +358,156 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16_t *__restr
   }
 }
 
+// ---- BN backward of a layer that also feeds a 2x2 max pool ---------------------------
+// The gradient through the pool is read where it is needed instead of being scattered into a full-resolution
+// tensor first: a lane owns one pooling window of 8 channels, loads the pooled gradient and the tie mask once
+// and adds the pooled gradient to the window positions whose mask bit is set.  dy1 (the other consumer's
+// gradient, full resolution) may be NULL.
+struct PoolSrc {
+  const bf16_t *dy;     // [N][H/2][W/2] pixels, ld channels apart
+  const uint8_t *mask;  // [N][H/2][W/2][CG*8]
+  int ld, W;            // W: width of the full-resolution image (even)
+};
+
+template <int ACT>
+__device__ __forceinline__ void pool_window_grads(const PoolSrc &ps, const bf16_t *__restrict__ dy1, int ld1,
+                                                  const bf16_t *__restrict__ z, int z_ld, i64 o, int cg, int CG,
+                                                  const ChanFwd (&c)[8], float (&g)[4][8], float (&zv)[4][8],
+                                                  i64 &pix) {
+  const int Wo = ps.W >> 1;
+  const i64 t = o / Wo;  // = n*H/2 + ho: pooled row, counted over the whole batch
+  const int wo = (int)(o - t * Wo);
+  pix = 2 * t * ps.W + 2 * wo;
+  const i64 off[4] = {0, 1, (i64)ps.W, (i64)ps.W + 1};
+  uint4 rz[4], r1[4];
+  const uint4 rp = *reinterpret_cast<const uint4 *>(ps.dy + o * ps.ld + cg * 8);
+  const uint2 mk = *reinterpret_cast<const uint2 *>(ps.mask + o * (CG * 8) + cg * 8);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) rz[k] = *reinterpret_cast<const uint4 *>(z + (pix + off[k]) * z_ld + cg * 8);
+  if (dy1) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) r1[k] = *reinterpret_cast<const uint4 *>(dy1 + (pix + off[k]) * ld1 + cg * 8);
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) r1[k] = make_uint4(0, 0, 0, 0);
+  }
+  float pg[8];
+  unpack8(rp, pg);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    unpack8(r1[k], g[k]);
+    unpack8(rz[k], zv[k]);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const uint32_t bit = ((j < 4 ? mk.x : mk.y) >> (8 * (j & 3) + k)) & 1u;
+      const float gin = g[k][j] + (bit ? pg[j] : 0.f);
+      g[k][j] = act_grad<ACT>(gin, fmaf(c[j].a, zv[k][j], c[j].b));
+    }
+  }
+}
+
+// pass 1 over windows: partial[b][c][2] = (sum g*xhat, sum g) over block b's windows
+template <int ACT>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_pool_kernel(const bf16_t *__restrict__ dy1, int ld1, PoolSrc ps,
+                                                                 const bf16_t *__restrict__ z, int z_ld,
+                                                                 const ChanFwd *__restrict__ cf, int CG, int PL,
+                                                                 i64 windows, i64 wpb, float *__restrict__ partial,
+                                                                 int CoP) {
+  extern __shared__ float red[];  // [PL][CG*16]
+  const int tid = threadIdx.x;
+  const int cg = tid % CG, pl = tid / CG;
+  float s[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) s[j] = 0.f;
+  if (pl < PL) {
+    ChanFwd c[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) c[j] = cf[cg * 8 + j];
+    const i64 o0 = (i64)blockIdx.x * wpb, o1 = min(windows, o0 + wpb);
+    for (i64 o = o0 + pl; o < o1; o += PL) {
+      float g[4][8], zv[4][8];
+      i64 pix;
+      pool_window_grads<ACT>(ps, dy1, ld1, z, z_ld, o, cg, CG, c, g, zv, pix);
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          s[2 * j] += g[k][j] * ((zv[k][j] - c[j].mean) * c[j].invb);
+          s[2 * j + 1] += g[k][j];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) red[(pl * CG + cg) * 16 + j] = s[j];
+  }
+  __syncthreads();
+  for (int t = tid; t < CG * 16; t += 256) {
+    float acc = 0.f;
+    for (int l = 0; l < PL; ++l) acc += red[l * CG * 16 + t];
+    const int ch = (t >> 4) * 8 + ((t & 15) >> 1);
+    partial[((i64)blockIdx.x * CoP + ch) * 2 + (t & 1)] = acc;
+  }
+}
+
+// pass 2 over windows: dz = c0*(g - k1 - xhat*k2) and, with BIAS, per-block sums of dz
+template <int ACT, bool BIAS>
+__global__ __launch_bounds__(256) void bn_bwd_apply_pool_kernel(const bf16_t *__restrict__ dy1, int ld1, PoolSrc ps,
+                                                                const bf16_t *__restrict__ z, int z_ld,
+                                                                const ChanFwd *__restrict__ cf,
+                                                                const ChanBwd *__restrict__ cb,
+                                                                bf16_t *__restrict__ dz, int dz_ld, int CG, int PL,
+                                                                i64 windows, i64 wpb, float *__restrict__ partial,
+                                                                int CoP) {
+  extern __shared__ float red[];  // [PL][CG*8]
+  const int tid = threadIdx.x;
+  const int cg = tid % CG, pl = tid / CG;
+  float s[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) s[j] = 0.f;
+  if (pl < PL) {
+    ChanFwd c[8];
+    ChanBwd b[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      c[j] = cf[cg * 8 + j];
+      b[j] = cb[cg * 8 + j];
+    }
+    const i64 o0 = (i64)blockIdx.x * wpb, o1 = min(windows, o0 + wpb);
+    for (i64 o = o0 + pl; o < o1; o += PL) {
+      float g[4][8], zv[4][8];
+      i64 pix;
+      pool_window_grads<ACT>(ps, dy1, ld1, z, z_ld, o, cg, CG, c, g, zv, pix);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float out[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float xh = (zv[k][j] - c[j].mean) * c[j].invb;
+          out[j] = b[j].c0 * (g[k][j] - b[j].k1 - xh * b[j].k2);
+        }
+        const uint4 packed = pack8(out);
+        *reinterpret_cast<uint4 *>(dz + (pix + (k >> 1) * (i64)ps.W + (k & 1)) * dz_ld + cg * 8) = packed;
+        if (BIAS) {
+          float r[8];
+          unpack8(packed, r);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) s[j] += r[j];
+        }
+      }
+    }
+    if (BIAS) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) red[(pl * CG + cg) * 8 + j] = s[j];
+    }
+  }
+  if (!BIAS) return;
+  __syncthreads();
+  for (int t = tid; t < CG * 8; t += 256) {
+    float acc = 0.f;
+    for (int l = 0; l < PL; ++l) acc += red[l * CG * 8 + t];
+    partial[(i64)blockIdx.x * CoP + t] = acc;
+  }
+}
+
 // out[c] = sum_p partial[p][c], c < C: one workgroup per channel
 __global__ __launch_bounds__(256) void column_sum_kernel(const float *__restrict__ partial, int P, int C, int stride,
                                                          float *__restrict__ out) {
@@ -414,6 +564,71 @@ __global__ __launch_bounds__(256) void maxpool2_kernel(const bf16_t *__restrict_
     }
     const i64 o = ((n * Ho + ho) * Wo + wo);
     *reinterpret_cast<uint4 *>(y + o * y_ld + cg * 8) = pack8(m);
+    *reinterpret_cast<uint2 *>(mask + o * (CG * 8) + cg * 8) = make_uint2(mk[0], mk[1]);
+  }
+}
+
+// bn_act and the 2x2 max pool that follows it in one pass: a lane owns one pooling window of 8 channels, writes the
+// four activations, their maximum and the tie mask (same values as bn_act_kernel followed by maxpool2_kernel:
+// the maximum is taken over the rounded bf16 activations).
+template <int ACT>
+__global__ __launch_bounds__(256) void bn_act_pool_kernel(const bf16_t *__restrict__ z, int z_ld,
+                                                          bf16_t *__restrict__ y, int y_ld,
+                                                          const ChanFwd *__restrict__ cf,
+                                                          bf16_t *__restrict__ yp, int yp_ld,
+                                                          uint8_t *__restrict__ mask, int CG, int H, int W,
+                                                          i64 total) {
+  const int Ho = H / 2, Wo = W / 2;
+  for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (i64)gridDim.x * blockDim.x) {
+    const int cg = (int)(i % CG);
+    i64 t = i / CG;
+    const int wo = (int)(t % Wo);
+    t /= Wo;
+    const int ho = (int)(t % Ho);
+    const i64 n = t / Ho;
+    const i64 pix = (n * H + 2 * ho) * W + 2 * wo;
+    const bf16_t *zp = z + pix * z_ld + cg * 8;
+    uint4 in[4];
+    in[0] = *reinterpret_cast<const uint4 *>(zp);
+    in[1] = *reinterpret_cast<const uint4 *>(zp + z_ld);
+    in[2] = *reinterpret_cast<const uint4 *>(zp + (i64)W * z_ld);
+    in[3] = *reinterpret_cast<const uint4 *>(zp + (i64)W * z_ld + z_ld);
+    float ca[8], cb[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const ChanFwd c = cf[cg * 8 + j];
+      ca[j] = c.a;
+      cb[j] = c.b;
+    }
+    float v[4][8];
+    bf16_t *yq = y + pix * y_ld + cg * 8;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float r[8];
+      unpack8(in[k], r);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float a = fmaf(ca[j], r[j], cb[j]);
+        if (ACT == 0) a = a > 0.f ? a : 0.f;
+        if (ACT == 1) a = 1.0f / (1.0f + __expf(-a));
+        r[j] = a;
+      }
+      const uint4 packed = pack8(r);
+      *reinterpret_cast<uint4 *>(yq + (i64)(k >> 1) * W * y_ld + (k & 1) * y_ld) = packed;
+      unpack8(packed, v[k]);
+    }
+    float m[8];
+    uint32_t mk[2] = {0, 0};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      m[j] = fmaxf(fmaxf(v[0][j], v[1][j]), fmaxf(v[2][j], v[3][j]));
+      uint32_t bits = 0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) bits |= (v[k][j] == m[j]) ? (1u << k) : 0u;
+      mk[j >> 2] |= bits << (8 * (j & 3));
+    }
+    const i64 o = ((n * Ho + ho) * Wo + wo);
+    *reinterpret_cast<uint4 *>(yp + o * yp_ld + cg * 8) = pack8(m);
     *reinterpret_cast<uint2 *>(mask + o * (CG * 8) + cg * 8) = make_uint2(mk[0], mk[1]);
   }
 }
@@ -584,6 +799,72 @@ int unet_bn_act_backward_bf16(const uint16_t *dy1, int ld1, const uint16_t *dy2,
   return UNET_OK;
 }
 
+int unet_bn_act_backward_pooled_bf16(const uint16_t *dy, int dy_ld, const uint16_t *pooled_dy, int pooled_ld,
+                                     const uint8_t *mask, int N, int H, int W, const uint16_t *z, int z_ld,
+                                     const float *coef, const float *gamma_beta, uint16_t *dz, int dz_ld,
+                                     float *grad_gb, float *grad_bias, int C, int CoP, int act, unet_stream_t s) {
+  int rc = UNET_OK;
+  if (dy) rc = check_view("unet_bn_act_backward_pooled_bf16 (dy)", dy, dy_ld, CoP);
+  if (!rc) rc = check_view("unet_bn_act_backward_pooled_bf16 (pooled_dy)", pooled_dy, pooled_ld, CoP);
+  if (!rc) rc = check_view("unet_bn_act_backward_pooled_bf16 (z)", z, z_ld, CoP);
+  if (!rc) rc = check_view("unet_bn_act_backward_pooled_bf16 (dz)", dz, dz_ld, CoP);
+  if (rc) return rc;
+  UNET_REQUIRE(mask && (((uintptr_t)mask) & 7) == 0 && N > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && coef &&
+                   gamma_beta && grad_gb && C > 0 && CoP >= C && CoP % 8 == 0 && CoP <= 2048 && act >= 0 && act <= 2,
+               "unet_bn_act_backward_pooled_bf16: need an 8-byte aligned mask, even H and W, CoP a multiple of 8 "
+               "(at most 2048)");
+  const i64 windows = (i64)N * (H / 2) * (W / 2), pixels = 4 * windows;
+  const RedPlan pl = plan_reduce(CoP, windows);
+  // workspace: partials [blocks][CoP][2] | ChanBwd [CoP] | bias partials [blocks][CoP]
+  const size_t n_part = (size_t)pl.blocks * CoP * 2, n_cb = (size_t)CoP * 4, n_bias = (size_t)pl.blocks * CoP;
+  void *ws;
+  rc = unet_workspace(&ws, sizeof(float) * (n_part + n_cb + n_bias), as_stream(s));
+  if (rc) return rc;
+  float *partial = (float *)ws, *cbf = partial + n_part, *bias_part = cbf + n_cb;
+  const ChanFwd *cf = reinterpret_cast<const ChanFwd *>(coef);
+  ChanBwd *cb = reinterpret_cast<ChanBwd *>(cbf);
+  const bf16_t *d1 = reinterpret_cast<const bf16_t *>(dy);
+  const bf16_t *zz = reinterpret_cast<const bf16_t *>(z);
+  const PoolSrc ps{reinterpret_cast<const bf16_t *>(pooled_dy), mask, pooled_ld, W};
+  const size_t lds1 = sizeof(float) * (size_t)pl.PL * pl.CG * 16, lds2 = sizeof(float) * (size_t)pl.PL * pl.CG * 8;
+  // bytes per element: z (+ dz), the full-resolution gradient, a quarter of a pooled gradient and of a mask byte
+  const double elems = (double)pixels * CoP, grads = (dy ? 2.0 : 0.0) + 0.75;
+#define BWD_LAUNCH(ACT_)                                                                                            \
+  do {                                                                                                              \
+    {                                                                                                               \
+      ProfScope prof(PROF_BN_BWD_REDUCE_BF16, 0, elems * (2.0 + grads), as_stream(s));                              \
+      hipLaunchKernelGGL(bn_bwd_reduce_pool_kernel<ACT_>, dim3(pl.blocks), dim3(256), lds1, as_stream(s), d1,       \
+                         dy_ld, ps, zz, z_ld, cf, pl.CG, pl.PL, windows, pl.ppb, partial, CoP);                     \
+    }                                                                                                               \
+    UNET_LAUNCH_CHECK("bn_bwd_reduce_pool_kernel");                                                                 \
+    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(CoP), dim3(256), 0, as_stream(s), (const float *)partial,       \
+                       pl.blocks, C, CoP, (float)pixels, gamma_beta, cf, grad_gb, cb);                              \
+    UNET_LAUNCH_CHECK("bn_finalize_bwd_kernel");                                                                    \
+    {                                                                                                               \
+      ProfScope prof(PROF_BN_BWD_APPLY_BF16, 0, elems * (4.0 + grads), as_stream(s));                               \
+      if (grad_bias)                                                                                                \
+        hipLaunchKernelGGL((bn_bwd_apply_pool_kernel<ACT_, true>), dim3(pl.blocks), dim3(256), lds2, as_stream(s),  \
+                           d1, dy_ld, ps, zz, z_ld, cf, (const ChanBwd *)cb, reinterpret_cast<bf16_t *>(dz), dz_ld, \
+                           pl.CG, pl.PL, windows, pl.ppb, bias_part, CoP);                                          \
+      else                                                                                                          \
+        hipLaunchKernelGGL((bn_bwd_apply_pool_kernel<ACT_, false>), dim3(pl.blocks), dim3(256), 0, as_stream(s),    \
+                           d1, dy_ld, ps, zz, z_ld, cf, (const ChanBwd *)cb, reinterpret_cast<bf16_t *>(dz), dz_ld, \
+                           pl.CG, pl.PL, windows, pl.ppb, (float *)nullptr, CoP);                                   \
+    }                                                                                                               \
+    UNET_LAUNCH_CHECK("bn_bwd_apply_pool_kernel");                                                                  \
+  } while (0)
+  if (act == 0) BWD_LAUNCH(0);
+  else if (act == 1) BWD_LAUNCH(1);
+  else BWD_LAUNCH(2);
+#undef BWD_LAUNCH
+  if (grad_bias) {
+    hipLaunchKernelGGL(column_sum_kernel, dim3(C), dim3(256), 0, as_stream(s), (const float *)bias_part,
+                       pl.blocks, C, CoP, grad_bias);
+    UNET_LAUNCH_CHECK("column_sum_kernel");
+  }
+  return UNET_OK;
+}
+
 int unet_bn_act_backward_from_partials_bf16(const uint16_t *dy, int dy_ld, const uint16_t *z, int z_ld,
                                             const float *coef, const float *gamma_beta,
                                             const float *red_partials, int num_partials, uint16_t *dz,
@@ -625,6 +906,34 @@ int unet_bn_act_backward_from_partials_bf16(const uint16_t *dy, int dy_ld, const
                        pl.blocks, C, CoP, grad_bias);
     UNET_LAUNCH_CHECK("column_sum_kernel");
   }
+  return UNET_OK;
+}
+
+int unet_bn_act_pool_bf16(const uint16_t *z, int z_ld, uint16_t *y, int y_ld, const float *coef, uint16_t *pooled,
+                          int pooled_ld, uint8_t *mask, int N, int H, int W, int CoP, int act, unet_stream_t s) {
+  int rc = check_view("unet_bn_act_pool_bf16 (z)", z, z_ld, CoP);
+  if (!rc) rc = check_view("unet_bn_act_pool_bf16 (y)", y, y_ld, CoP);
+  if (!rc) rc = check_view("unet_bn_act_pool_bf16 (pooled)", pooled, pooled_ld, CoP);
+  if (rc) return rc;
+  UNET_REQUIRE(coef && mask && N > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && CoP > 0 && CoP % 8 == 0 &&
+                   CoP <= 2048 && act >= 0 && act <= 2 && (((uintptr_t)mask) & 7) == 0,
+               "unet_bn_act_pool_bf16: need even H and W, channels a multiple of 8 (at most 2048), an 8-byte "
+               "aligned mask");
+  const i64 total = (i64)N * (H / 2) * (W / 2) * (CoP / 8);
+  const ChanFwd *cf = reinterpret_cast<const ChanFwd *>(coef);
+  // read z, write y, write a quarter of y again (pooled) and a quarter of a byte of mask per element
+  ProfScope prof(PROF_BN_ACT_BF16, 0, (double)N * H * W * CoP * 4.75, as_stream(s));
+  const dim3 grid(ew_grid(total));
+  if (act == 0)
+    hipLaunchKernelGGL(bn_act_pool_kernel<0>, grid, dim3(256), 0, as_stream(s), z, z_ld, y, y_ld, cf, pooled,
+                       pooled_ld, mask, CoP / 8, H, W, total);
+  else if (act == 1)
+    hipLaunchKernelGGL(bn_act_pool_kernel<1>, grid, dim3(256), 0, as_stream(s), z, z_ld, y, y_ld, cf, pooled,
+                       pooled_ld, mask, CoP / 8, H, W, total);
+  else
+    hipLaunchKernelGGL(bn_act_pool_kernel<2>, grid, dim3(256), 0, as_stream(s), z, z_ld, y, y_ld, cf, pooled,
+                       pooled_ld, mask, CoP / 8, H, W, total);
+  UNET_LAUNCH_CHECK("bn_act_pool_kernel");
   return UNET_OK;
 }
 

@@ -128,6 +128,9 @@ struct Node {
   int bwd_partials_n = 0;        // number of partial rows in it; 0 = none this step
   int concat_child = -1;         // index of the CONCAT consumer (at most one on this path)
   int concat_slot = 0;           // 0: first parent (skip), 1: second parent
+  int pool_child = -1;           // a MAX_POOL consumer whose forward runs inside this layer's BN + activation pass
+  bool pooled_by_parent = false; // (pool) the parent's pass already wrote this layer's output and mask
+  const Node *pool_src = nullptr;  // (backward) the pool whose gradient this layer still has to gather
   int64_t in_elems() const { return (int64_t)in_c * in_h * in_w; }
   int64_t out_elems() const { return (int64_t)out_c * out_h * out_w; }
   bool has_params() const { return type == CONV_LAYER || type == UPSAMPLING_LAYER; }
@@ -282,6 +285,7 @@ class Net {
       for (Node &n : nodes_) {
         n.g_written = false;
         n.g2_ptr = nullptr;
+        n.pool_src = nullptr;
         n.bwd_partials_n = 0;
       }
     for (int i = (int)nodes_.size() - 1; i >= 0; --i) {
@@ -840,6 +844,7 @@ class Net {
   bool plan_bf16(std::string &why) {
     for (Node &n : nodes_) {
       n.concat_child = -1;
+      n.pool_child = -1;
       n.narrow = false;
       n.head = false;
     }
@@ -889,6 +894,11 @@ class Net {
       n.cop = pad32(n.out_c);
       n.head = n.narrow && n.type == CONV_LAYER && n.out_c == 1 && !n.parents.empty() &&
                unet_conv3x3_head_supported(n.cip) != 0;
+    }
+    for (size_t i = 0; i < nodes_.size(); ++i) {
+      if (nodes_[i].type != MAX_POOL_LAYER) continue;
+      Node &p = nodes_[nodes_[i].parents[0]];
+      if (p.has_params() && !p.narrow && p.pool_child < 0) p.pool_child = (int)i;
     }
     return true;
   }
@@ -1035,10 +1045,22 @@ class Net {
           UNET_CALL(unet_bn_finalize_bf16(parts, num_parts, n.out_c, n.cop, out_pix, gb, n.batch_stats.f32(),
                                           n.running.f32(), n.coef.f32(), stream_));
         const int act = (n.type == CONV_LAYER && n.activation == SIGMOID) ? 1 : 0;
+        if (n.pool_child >= 0) {
+          // the skip layers of the encoder: activation, pooled activation and tie mask from one pass over z
+          Node &q = nodes_[n.pool_child];
+          UNET_CALL(unet_bn_act_pool_bf16(n.zb.u16(), n.cop, n.y_ptr, n.y_ld, n.coef.f32(), q.y_ptr, q.y_ld, q.mask.u8(),
+                                          batch, n.out_h, n.out_w, n.cop, act, stream_));
+          q.pooled_by_parent = true;
+          break;
+        }
         UNET_CALL(unet_bn_act_bf16(n.zb.u16(), n.cop, n.y_ptr, n.y_ld, n.coef.f32(), n.cop, out_pix, act, stream_));
         break;
       }
       case MAX_POOL_LAYER: {
+        if (n.pooled_by_parent) {
+          n.pooled_by_parent = false;
+          break;
+        }
         const Node &p = nodes_[n.parents[0]];
         UNET_CALL(unet_max_pool2x2_bf16(p.y_ptr, p.y_ld, n.y_ptr, n.y_ld, n.mask.u8(), batch, n.in_h, n.in_w, n.cop,
                                         stream_));
@@ -1107,12 +1129,27 @@ class Net {
           for (int c = 0; c < n.out_c; ++c)
             UNET_CALL(unet_memcpy_d2d(gbias + c, n.coef.f32() + 2 * c, sizeof(float), stream_));
         } else {
+          if (n.pool_src && n.g_written && n.g2_ptr) {
+            // three gradient sources: scatter the pooled one after all
+            const Node &q = *n.pool_src;
+            UNET_CALL(unet_max_pool2x2_backward_bf16(q.gb.u16(), q.cop, q.mask.u8(), n.gb.u16(), n.cop, batch, q.in_h,
+                                                     q.in_w, q.cop, 1, stream_));
+            n.pool_src = nullptr;
+          }
           const uint16_t *d1 = n.g_written ? n.gb.u16() : n.g2_ptr;
           const int l1 = n.g_written ? n.cop : n.g2_ld;
           const uint16_t *d2 = (n.g_written && n.g2_ptr) ? n.g2_ptr : nullptr;
-          if (!d1) return;  // not on a path to the loss
+          if (!d1 && !n.pool_src) return;  // not on a path to the loss
           const int act = (n.type == CONV_LAYER && n.activation == SIGMOID) ? 1 : 0;
-          if (n.bwd_partials_n > 0)  // the consumer's data-gradient kernel already reduced over the pixels
+          if (n.pool_src) {
+            // a skip layer: the gradient through the max pool is gathered from the pooled gradient and the tie
+            // mask inside the batch-norm backward passes, next to the concat slice d1 (if any)
+            const Node &q = *n.pool_src;
+            UNET_CALL(unet_bn_act_backward_pooled_bf16(d1, l1, q.gb.u16(), q.cop, q.mask.u8(), batch, n.out_h, n.out_w,
+                                                       n.zb.u16(), n.cop, n.coef.f32(), w + n.num_wb, dz, n.cop,
+                                                       gw + n.num_wb, kNoBiasGrad, n.out_c, n.cop, act, stream_));
+            n.pool_src = nullptr;
+          } else if (n.bwd_partials_n > 0)  // the consumer's data-gradient kernel already reduced over the pixels
             UNET_CALL(unet_bn_act_backward_from_partials_bf16(d1, l1, n.zb.u16(), n.cop, n.coef.f32(), w + n.num_wb,
                                                               n.bwd_partials.f32(), n.bwd_partials_n, dz, n.cop,
                                                               gw + n.num_wb, kNoBiasGrad, n.out_c, n.cop, out_pix,
@@ -1170,6 +1207,10 @@ class Net {
       case MAX_POOL_LAYER: {
         if (!n.g_written) return;
         Node &p = nodes_[n.parents[0]];
+        if (p.has_params() && !p.narrow && !p.pool_src) {
+          p.pool_src = &n;  // gathered by the parent's batch-norm backward
+          break;
+        }
         UNET_CALL(unet_max_pool2x2_backward_bf16(n.gb.u16(), n.cop, n.mask.u8(), p.gb.u16(), p.cop, batch, n.in_h, n.in_w,
                                                  n.cop, p.g_written ? 1 : 0, stream_));
         p.g_written = true;
