@@ -266,3 +266,33 @@ def threshold(x, thr):
     x = _c(x).copy()
     lib().oracle_threshold(_p(x), _F(thr), _L(x.size))
     return x
+
+
+def attention_params(cx, cg, ci):
+    """Number of parameters of an attention gate (layer.h:558-566)."""
+    return (cx + cg + 2) * ci + 1
+
+
+def attention(x, g, params, ci):
+    """Attention gate forward -> (out [N,Cx,H,W], int1 [N,Ci,H/2,W/2], alpha [N,H/2,W/2])."""
+    x, g, params = _c(x), _c(g), _c(params)
+    n, cx, h, w = x.shape
+    cg = g.shape[1]
+    assert g.shape == (n, cg, h // 2, w // 2) and params.size == attention_params(cx, cg, ci)
+    int1 = np.empty((n, ci, h // 2, w // 2), np.float32)
+    alpha = np.empty((n, h // 2, w // 2), np.float32)
+    out = np.empty_like(x)
+    lib().oracle_attention(_p(x), _p(g), _p(params), _p(int1), _p(alpha), _p(out), _I(n), _I(h), _I(w),
+                           _I(cx), _I(cg), _I(ci))
+    return out, int1, alpha
+
+
+def attention_backward(grad_out, int1, alpha, x, g, params):
+    """-> (grad_x, grad_g, grad_params)."""
+    grad_out, int1, alpha, x, g, params = _c(grad_out), _c(int1), _c(alpha), _c(x), _c(g), _c(params)
+    n, cx, h, w = x.shape
+    cg, ci = g.shape[1], int1.shape[1]
+    gx, gg, gp = np.empty_like(x), np.empty_like(g), np.empty_like(params)
+    lib().oracle_attention_backward(_p(grad_out), _p(int1), _p(alpha), _p(x), _p(g), _p(params), _p(gx), _p(gg),
+                                    _p(gp), _I(n), _I(h), _I(w), _I(cx), _I(cg), _I(ci))
+    return gx, gg, gp

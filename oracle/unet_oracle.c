@@ -498,3 +498,144 @@ void oracle_add_b_to_a(float *a, const float *b, i64 n) {
 void oracle_threshold(float *x, float thr, i64 n) {
   for (i64 i = 0; i < n; ++i) x[i] = x[i] >= thr ? 1.0f : 0.0f;
 }
+
+/* -------------------------------------------------------- attention gate -- */
+
+/* The reference's additive attention gate, src/cuda_library/attention/attention.cu:9-203
+ * (the reference has no CPU loop for it: src/cuda_library/test/attention_test.h:12-22 is empty,
+ * so this follows the kernels).  x [N,Cx,Hx,Wx] is the skip tensor, g [N,Cg,Hx/2,Wx/2] the gating
+ * tensor; Ci intermediate channels (the layer passes Cx/2, attention_layer_functions.h:18).
+ * params (layer.h:558-566): W[(Cx+Cg)][Ci] (x rows, then g rows) | psi[Ci] | b1[Ci] | bpsi.
+ *   int1[n,o,h,w] = relu(b1[o] + sum_i x[n,i,2h,2w] W[i][o] + sum_j g[n,j,h,w] W[Cx+j][o])   (:84-132)
+ *   alpha[n,h,w]  = sigmoid(bpsi + sum_o int1[n,o,h,w] psi[o])                              (:9-43)
+ *   out[n,c,h,w]  = x[n,c,h,w] * interp(alpha)(h,w)                                         (:45-81)
+ * interp: the 4x4 block of output pixels that contains (h,w) blends the 2x2 alpha cells whose
+ * top-left is (2*(h/4), 2*(w/4)) with fractions (h%4)/3 and (w%4)/3.
+ * Deviations: double accumulators; the "+1" cells are clamped to the last row/column -- the
+ * reference computes the clamped indices (:65-66) but indexes with the unclamped ones, which only
+ * differs (reads out of bounds) when Hx/2 or Wx/2 is odd; int1/alpha are overwritten, not
+ * accumulated into. */
+static inline void attn_corner(int h, int H_g, int *a0, int *a1, float *frac) {
+  const int small = h / 2;
+  *a0 = small & ~1;
+  *a1 = (*a0 + 1 < H_g) ? *a0 + 1 : H_g - 1;
+  *frac = (float)(h % 4) / 3.0f;
+}
+
+static double attn_interp(const float *alpha, i64 n, int h, int w, int H_g, int W_g) {
+  int h0, h1, w0, w1;
+  float fh, fw;
+  attn_corner(h, H_g, &h0, &h1, &fh);
+  attn_corner(w, W_g, &w0, &w1, &fw);
+  const float *a = alpha + n * (i64)H_g * W_g;
+  const double A = a[(i64)h0 * W_g + w0], B = a[(i64)h0 * W_g + w1];
+  const double C = a[(i64)h1 * W_g + w0], D = a[(i64)h1 * W_g + w1];
+  const double r1 = B * fw + A * (1.0 - fw), r2 = D * fw + C * (1.0 - fw);
+  return r2 * fh + r1 * (1.0 - fh);
+}
+
+void oracle_attention(const float *x, const float *g, const float *params, float *int1,
+                      float *alpha, float *out, int batch, int H_x, int W_x, int C_x, int C_g,
+                      int C_i) {
+  const int H_g = H_x / 2, W_g = W_x / 2;
+  const float *psi = params + (i64)(C_x + C_g) * C_i;
+  const float *b1 = psi + C_i;
+  const float bpsi = b1[C_i];
+  for (i64 n = 0; n < batch; ++n)
+    for (int h = 0; h < H_g; ++h)
+      for (int w = 0; w < W_g; ++w) {
+        double z = bpsi;
+        for (int o = 0; o < C_i; ++o) {
+          double acc = b1[o];
+          for (int i = 0; i < C_x; ++i)
+            acc += (double)x[flat(n, i, C_x, 2 * h, H_x, 2 * w, W_x)] * (double)params[(i64)i * C_i + o];
+          for (int j = 0; j < C_g; ++j)
+            acc += (double)g[flat(n, j, C_g, h, H_g, w, W_g)] * (double)params[(i64)(C_x + j) * C_i + o];
+          const float r = acc > 0 ? (float)acc : 0.0f;
+          int1[flat(n, o, C_i, h, H_g, w, W_g)] = r;
+          z += (double)r * (double)psi[o];
+        }
+        alpha[(n * H_g + h) * W_g + w] = (float)(1.0 / (1.0 + exp(-z)));
+      }
+  for (i64 n = 0; n < batch; ++n)
+    for (int h = 0; h < H_x; ++h)
+      for (int w = 0; w < W_x; ++w) {
+        const double a = attn_interp(alpha, n, h, w, H_g, W_g);
+        for (int c = 0; c < C_x; ++c) {
+          const i64 idx = flat(n, c, C_x, h, H_x, w, W_x);
+          out[idx] = (float)((double)x[idx] * a);
+        }
+      }
+}
+
+/* attention.cu:205-480 (cudaAttentionBackward): resample backward (grad_x = grad_out * interp,
+ * grad_alpha scattered to the four cells with their blend weights), sigmoid + psi backward,
+ * ReLU + gate backward (weight, bias and input gradients; the x gradient of the stride-2 1x1
+ * projection adds onto grad_x at the even pixels).  All outputs overwritten; double accumulators. */
+void oracle_attention_backward(const float *grad_out, const float *int1, const float *alpha,
+                               const float *x, const float *g, const float *params,
+                               float *grad_x, float *grad_g, float *grad_params, int batch,
+                               int H_x, int W_x, int C_x, int C_g, int C_i) {
+  const int H_g = H_x / 2, W_g = W_x / 2;
+  const i64 cells = (i64)batch * H_g * W_g;
+  const i64 n_params = (i64)(C_x + C_g + 2) * C_i + 1;
+  const float *psi = params + (i64)(C_x + C_g) * C_i;
+  double *ga = (double *)calloc((size_t)cells, sizeof(double));
+  double *gp = (double *)calloc((size_t)n_params, sizeof(double));
+  double *gx = (double *)calloc((size_t)batch * C_x * H_x * W_x, sizeof(double));
+  for (i64 n = 0; n < batch; ++n)
+    for (int h = 0; h < H_x; ++h)
+      for (int w = 0; w < W_x; ++w) {
+        int h0, h1, w0, w1;
+        float fh, fw;
+        attn_corner(h, H_g, &h0, &h1, &fh);
+        attn_corner(w, W_g, &w0, &w1, &fw);
+        const double a = attn_interp(alpha, n, h, w, H_g, W_g);
+        double s = 0;
+        for (int c = 0; c < C_x; ++c) {
+          const i64 idx = flat(n, c, C_x, h, H_x, w, W_x);
+          gx[idx] = (double)grad_out[idx] * a;
+          s += (double)grad_out[idx] * (double)x[idx];
+        }
+        double *cell = ga + n * (i64)H_g * W_g;
+        cell[(i64)h0 * W_g + w0] += s * (1.0 - fw) * (1.0 - fh);
+        cell[(i64)h0 * W_g + w1] += s * fw * (1.0 - fh);
+        cell[(i64)h1 * W_g + w0] += s * (1.0 - fw) * fh;
+        cell[(i64)h1 * W_g + w1] += s * fw * fh;
+      }
+  for (i64 n = 0; n < batch; ++n)
+    for (int h = 0; h < H_g; ++h)
+      for (int w = 0; w < W_g; ++w) {
+        const double al = alpha[(n * H_g + h) * W_g + w];
+        const double gz = ga[(n * H_g + h) * W_g + w] * al * (1.0 - al);
+        gp[(i64)(C_x + C_g + 2) * C_i] += gz;  /* bpsi */
+        for (int o = 0; o < C_i; ++o) {
+          const double act = int1[flat(n, o, C_i, h, H_g, w, W_g)];
+          gp[(i64)(C_x + C_g) * C_i + o] += gz * act;  /* psi */
+          const double gpre = act > 0 ? gz * (double)psi[o] : 0.0;
+          if (gpre == 0.0) continue;
+          gp[(i64)(C_x + C_g + 1) * C_i + o] += gpre;  /* b1 */
+          for (int i = 0; i < C_x; ++i) {
+            const i64 xi = flat(n, i, C_x, 2 * h, H_x, 2 * w, W_x);
+            gp[(i64)i * C_i + o] += gpre * (double)x[xi];
+            gx[xi] += gpre * (double)params[(i64)i * C_i + o];
+          }
+        }
+        for (int j = 0; j < C_g; ++j) {
+          double acc = 0;
+          const double gv = g[flat(n, j, C_g, h, H_g, w, W_g)];
+          for (int o = 0; o < C_i; ++o) {
+            const double act = int1[flat(n, o, C_i, h, H_g, w, W_g)];
+            const double gpre = act > 0 ? gz * (double)psi[o] : 0.0;
+            gp[(i64)(C_x + j) * C_i + o] += gpre * gv;
+            acc += gpre * (double)params[(i64)(C_x + j) * C_i + o];
+          }
+          grad_g[flat(n, j, C_g, h, H_g, w, W_g)] = (float)acc;
+        }
+      }
+  for (i64 k = 0; k < (i64)batch * C_x * H_x * W_x; ++k) grad_x[k] = (float)gx[k];
+  for (i64 k = 0; k < n_params; ++k) grad_params[k] = (float)gp[k];
+  free(ga);
+  free(gp);
+  free(gx);
+}

@@ -20,6 +20,12 @@ def golden():
 
 
 @pytest.fixture(scope="session")
+def golden_attention():
+    path = os.path.join(ROOT, "tests", "golden", "attention_small.npz")
+    return np.load(path, allow_pickle=False)
+
+
+@pytest.fixture(scope="session")
 def oracle():
     import oracle as _o
     _o.lib()

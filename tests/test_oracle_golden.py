@@ -115,3 +115,22 @@ def test_dice_reference_formula_is_exact_derivative(golden):
     """Documents that the reference's backward formula (given the sums) IS the
     exact per-sample derivative of the Dice score -- autograd agrees."""
     assert_close(golden["dice_grad_ref"], golden["dice_grad_full"], rtol=1e-4, what="dice derivative")
+
+
+ATTENTION = ["attn_a", "attn_odd", "attn_b"]
+
+
+@pytest.mark.parametrize("name", ATTENTION)
+def test_attention_gate(oracle, golden_attention, name):
+    """tests/golden/attention_small.npz (tests/golden/make_golden_attention.py): torch operators + autograd."""
+    G = golden_attention
+    ci = int(G[name + "_cfg"][3])
+    x, g, params = G[name + "_x"], G[name + "_g"], G[name + "_params"]
+    y, int1, alpha = oracle.attention(x, g, params, ci)
+    assert_close(int1, G[name + "_int1"], what=name + " int1")
+    assert_close(alpha, G[name + "_alpha"], what=name + " alpha")
+    assert_close(y, G[name + "_y"], what=name + " y")
+    dx, dg, dp = oracle.attention_backward(G[name + "_dy"], int1, alpha, x, g, params)
+    assert_close(dx, G[name + "_dx"], what=name + " dx")
+    assert_close(dg, G[name + "_dg"], what=name + " dg")
+    assert_close(dp, G[name + "_dparams"], what=name + " dparams")
