@@ -191,6 +191,32 @@ int unet_max_pool_backward_indices_f32(const float *grad_activations, const int3
                                        int in_height, int in_width, int out_height,
                                        int out_width, unet_stream_t stream);
 
+/* ---- attention gate ------------------------------------------------------ */
+/* cudaAttention / cudaAttentionBackward (cuda_lib.h:121-132, 227-243;
+ * attention.cu:9-499), same argument lists.  x [N,Cx,H_x,W_x] is gated by
+ * g [N,Cg,H_x/2,W_x/2]:
+ *   int_1 [N,Ci,H_x/2,W_x/2] = relu(b1 + 1x1 stride-2 projection of x + 1x1 projection of g)
+ *   int_2 [N,H_x/2,W_x/2]    = sigmoid(bpsi + psi . int_1)
+ *   activations [N,Cx,H_x,W_x] = x * blend(int_2), blend = the reference's 4x4-block mix of
+ *   2x2 cells (attention.cu:61-78) with the "+1" cells clamped to the last row / column.
+ * weights (layer.h:558-566): W[(Cx+Cg)][Ci] | psi[Ci] | b1[Ci] | bpsi =
+ * unet_attention_param_count() floats.  All outputs are overwritten (the reference accumulates
+ * into zeroed buffers with atomicAdd); every sum has a fixed order.  In the backward,
+ * grad_activations_int_1 receives the gradient at the ReLU input and grad_activations_int_2
+ * the gradient of int_2; grad_input_x includes the stride-2 projection's term. */
+int64_t unet_attention_param_count(int channels_in_x, int channels_in_g, int int_channels);
+int unet_attention_f32(float *activations_int_1, float *activations_int_2, float *activations,
+                       const float *weights, const float *input_x, const float *input_g,
+                       int batch_size, int H_x, int W_x, int channels_in_x, int channels_in_g,
+                       int int_channels, unet_stream_t stream);
+int unet_attention_backward_f32(const float *grad_activations, const float *activations_int_1,
+                                const float *activations_int_2, const float *input_x,
+                                const float *input_g, const float *weights,
+                                float *grad_activations_int_1, float *grad_activations_int_2,
+                                float *grad_input_x, float *grad_input_g, float *grad_weights,
+                                int batch_size, int H_x, int W_x, int channels_in_x,
+                                int channels_in_g, int int_channels, unet_stream_t stream);
+
 /* ---- upsample = transposed conv, kernel = stride = scale ---------------- */
 /* (cuda_lib.h:79-88, 213-224) */
 

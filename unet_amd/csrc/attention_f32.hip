@@ -1,0 +1,437 @@
+// Additive attention gate, fp32 NCHW (the reference's cudaAttention / cudaAttentionBackward,
+// src/cuda_library/attention/attention.cu:9-499).
+//
+//   int1[n,o,h,w] = relu(b1[o] + sum_i x[n,i,2h,2w] W[i][o] + sum_j g[n,j,h,w] W[Cx+j][o])
+//   alpha[n,h,w]  = sigmoid(bpsi + sum_o int1[n,o,h,w] psi[o])
+//   out[n,c,h,w]  = x[n,c,h,w] * blend(alpha)(h,w)
+//
+// x [N,Cx,Hx,Wx], g [N,Cg,Hx/2,Wx/2]; "cells" below are the N*Hx/2*Wx/2 pixels of g.
+// Parameters (layer.h:558-566): W[(Cx+Cg)][Ci] | psi[Ci] | b1[Ci] | bpsi.
+// blend: the 4x4 block of output pixels that contains (h,w) mixes the 2x2 cells whose top-left is
+// (2*(h/4), 2*(w/4)) with the fractions (h%4)/3 and (w%4)/3 (attention.cu:61-78); the "+1" cells are
+// clamped to the last row / column, which the reference computes (:65-66) but does not use (it reads
+// out of bounds when Hx/2 or Wx/2 is odd).
+//
+// Unlike the reference's backward (fp32 atomicAdd everywhere) every sum here has a fixed order:
+// gathers instead of scatters, one workgroup per output tile for the weight gradient, split
+// partials added in index order.
+#include "common.h"
+
+namespace {
+
+constexpr int CELLS = 64;  // cells per workgroup in the gate kernels (one wavefront wide)
+
+struct Blend {
+  int c0, c1;
+  float f;
+};
+__device__ __forceinline__ Blend blend_axis(int i, int cells) {
+  Blend b;
+  b.c0 = (i >> 2) << 1;
+  b.c1 = min(b.c0 + 1, cells - 1);
+  b.f = (float)(i & 3) / 3.0f;
+  return b;
+}
+__device__ __forceinline__ float blend_value(const float *__restrict__ alpha_n, int h, int w, int Hg, int Wg) {
+  const Blend bh = blend_axis(h, Hg), bw = blend_axis(w, Wg);
+  const float A = alpha_n[(i64)bh.c0 * Wg + bw.c0], B = alpha_n[(i64)bh.c0 * Wg + bw.c1];
+  const float C = alpha_n[(i64)bh.c1 * Wg + bw.c0], D = alpha_n[(i64)bh.c1 * Wg + bw.c1];
+  const float r1 = B * bw.f + A * (1.0f - bw.f), r2 = D * bw.f + C * (1.0f - bw.f);
+  return r2 * bh.f + r1 * (1.0f - bh.f);
+}
+
+// Input channel k of cell (n, h, w): x at the even pixels for k < Cx, g otherwise.
+struct GateIn {
+  const float *x, *g;
+  int Cx, Cg, Hg, Wg;
+};
+__device__ __forceinline__ float gate_input(const GateIn &in, int k, i64 n, int h, int w) {
+  if (k < in.Cx) return in.x[((n * in.Cx + k) * (2 * in.Hg) + 2 * h) * (i64)(2 * in.Wg) + 2 * w];
+  return in.g[((n * in.Cg + (k - in.Cx)) * in.Hg + h) * (i64)in.Wg + w];
+}
+
+// ---- forward ---------------------------------------------------------------------------------
+// 256 threads = 64 consecutive cells x 4 channel groups; a thread walks its group's intermediate
+// channels eight at a time (the weights of a group are uniform over a wavefront).  The psi dot
+// product is summed over the four groups through LDS in group order.
+__global__ __launch_bounds__(256) void attn_gate_fwd_kernel(GateIn in, const float *__restrict__ params, int Ci,
+                                                            float *__restrict__ int1, float *__restrict__ alpha,
+                                                            i64 cells) {
+  __shared__ float zpart[4][CELLS];
+  const int K = in.Cx + in.Cg;
+  const float *psi = params + (i64)K * Ci, *b1 = psi + Ci;
+  const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const i64 cell = (i64)blockIdx.x * CELLS + lane;
+  const bool live = cell < cells;
+  const i64 hw = (i64)in.Hg * in.Wg;
+  const i64 n = live ? cell / hw : 0;
+  const int rem = live ? (int)(cell - n * hw) : 0;
+  const int h = rem / in.Wg, w = rem - h * in.Wg;
+  const int per = (Ci + 3) / 4, o_begin = grp * per, o_end = min(Ci, o_begin + per);
+  float z = 0.f;
+  for (int o0 = o_begin; o0 < o_end; o0 += 8) {
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = (o0 + j < o_end) ? b1[o0 + j] : 0.f;
+    for (int k = 0; k < K; ++k) {
+      const float v = live ? gate_input(in, k, n, h, w) : 0.f;
+      const float *wr = params + (i64)k * Ci + o0;
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (o0 + j < o_end) acc[j] = fmaf(v, wr[j], acc[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (o0 + j < o_end) {
+        const float r = acc[j] > 0.f ? acc[j] : 0.f;
+        if (live) int1[(n * Ci + o0 + j) * hw + rem] = r;
+        z = fmaf(r, psi[o0 + j], z);
+      }
+  }
+  zpart[grp][lane] = z;
+  __syncthreads();
+  if (grp == 0 && live) {
+    const float t = b1[Ci] + ((zpart[0][lane] + zpart[1][lane]) + (zpart[2][lane] + zpart[3][lane]));
+    alpha[cell] = 1.0f / (1.0f + expf(-t));
+  }
+}
+
+// out = x * blend(alpha); one thread per (n, h, w) pixel, looping over the channels.
+__global__ __launch_bounds__(256) void attn_resample_mul_kernel(const float *__restrict__ x,
+                                                                const float *__restrict__ alpha,
+                                                                float *__restrict__ out, int Cx, int Hx, int Wx,
+                                                                i64 pixels) {
+  const int Hg = Hx / 2, Wg = Wx / 2;
+  const i64 hw = (i64)Hx * Wx;
+  for (i64 p = (i64)blockIdx.x * blockDim.x + threadIdx.x; p < pixels; p += (i64)gridDim.x * blockDim.x) {
+    const i64 n = p / hw;
+    const int rem = (int)(p - n * hw);
+    const int h = rem / Wx, w = rem - h * Wx;
+    const float a = blend_value(alpha + n * (i64)Hg * Wg, h, w, Hg, Wg);
+    const i64 base = n * Cx * hw + rem;
+    int c = 0;
+    for (; c + 3 < Cx; c += 4) {
+      float v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = x[base + (c + u) * hw];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) out[base + (c + u) * hw] = v[u] * a;
+    }
+    for (; c < Cx; ++c) out[base + c * hw] = x[base + c * hw] * a;
+  }
+}
+
+// ---- backward --------------------------------------------------------------------------------
+// grad_x = grad_out * blend(alpha) and s[n,h,w] = sum_c grad_out * x (what the blend weights of
+// pixel (h,w) receive); one thread per pixel, channels in order.
+__global__ __launch_bounds__(256) void attn_resample_bwd_kernel(const float *__restrict__ grad_out,
+                                                                const float *__restrict__ x,
+                                                                const float *__restrict__ alpha,
+                                                                float *__restrict__ grad_x, float *__restrict__ s,
+                                                                int Cx, int Hx, int Wx, i64 pixels) {
+  const int Hg = Hx / 2, Wg = Wx / 2;
+  const i64 hw = (i64)Hx * Wx;
+  for (i64 p = (i64)blockIdx.x * blockDim.x + threadIdx.x; p < pixels; p += (i64)gridDim.x * blockDim.x) {
+    const i64 n = p / hw;
+    const int rem = (int)(p - n * hw);
+    const int h = rem / Wx, w = rem - h * Wx;
+    const float a = blend_value(alpha + n * (i64)Hg * Wg, h, w, Hg, Wg);
+    const i64 base = n * Cx * hw + rem;
+    float acc = 0.f;
+    int c = 0;
+    for (; c + 3 < Cx; c += 4) {
+      float go[4], xv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        go[u] = grad_out[base + (c + u) * hw];
+        xv[u] = x[base + (c + u) * hw];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        grad_x[base + (c + u) * hw] = go[u] * a;
+        acc = fmaf(go[u], xv[u], acc);
+      }
+    }
+    for (; c < Cx; ++c) {
+      const float go = grad_out[base + c * hw];
+      grad_x[base + c * hw] = go * a;
+      acc = fmaf(go, x[base + c * hw], acc);
+    }
+    s[p] = acc;
+  }
+}
+
+// One thread per cell: gathers grad_alpha from the 4x4 pixel block that blends this cell (each cell
+// belongs to exactly one block; with the clamp it can hold two corner roles of it), then sigmoid
+// backward, and the gradient at the ReLU input for every intermediate channel:
+//   grad_alpha -> galpha,  gpre[n,o,cell] = int1 > 0 ? grad_alpha * alpha * (1 - alpha) * psi[o] : 0
+__global__ __launch_bounds__(256) void attn_cell_bwd_kernel(const float *__restrict__ s,
+                                                            const float *__restrict__ alpha,
+                                                            const float *__restrict__ int1,
+                                                            const float *__restrict__ psi, float *__restrict__ galpha,
+                                                            float *__restrict__ gpre, int Ci, int Hx, int Wx,
+                                                            i64 cells) {
+  const int Hg = Hx / 2, Wg = Wx / 2;
+  const i64 hw = (i64)Hg * Wg;
+  for (i64 cell = (i64)blockIdx.x * blockDim.x + threadIdx.x; cell < cells; cell += (i64)gridDim.x * blockDim.x) {
+    const i64 n = cell / hw;
+    const int rem = (int)(cell - n * hw);
+    const int hs = rem / Wg, ws = rem - hs * Wg;
+    const int bh = hs >> 1, bw = ws >> 1;
+    const float *sn = s + n * (i64)Hx * Wx;
+    float ga = 0.f;
+    for (int rh = 0; rh < 2; ++rh) {
+      if ((rh == 0 ? 2 * bh : min(2 * bh + 1, Hg - 1)) != hs) continue;
+      for (int rw = 0; rw < 2; ++rw) {
+        if ((rw == 0 ? 2 * bw : min(2 * bw + 1, Wg - 1)) != ws) continue;
+        for (int dh = 0; dh < 4; ++dh) {
+          const int h = 4 * bh + dh;
+          if (h >= Hx) break;
+          const float fh = (float)dh / 3.0f, wh = rh ? fh : 1.0f - fh;
+          for (int dw = 0; dw < 4; ++dw) {
+            const int w = 4 * bw + dw;
+            if (w >= Wx) break;
+            const float fw = (float)dw / 3.0f, ww = rw ? fw : 1.0f - fw;
+            ga = fmaf(sn[(i64)h * Wx + w], ww * wh, ga);
+          }
+        }
+      }
+    }
+    galpha[cell] = ga;
+    const float al = alpha[cell];
+    const float gz = ga * al * (1.0f - al);
+    for (int o = 0; o < Ci; ++o) {
+      const i64 idx = (n * Ci + o) * hw + rem;
+      gpre[idx] = int1[idx] > 0.f ? gz * psi[o] : 0.f;
+    }
+  }
+}
+
+// Input gradients of the two 1x1 projections: dst[k] (+)= sum_o gpre[o] * W[k][o] per cell.
+// Same thread layout as the forward: 64 cells x 4 groups of input channels, eight at a time.
+// The x part lands on the even pixels of grad_x, which already holds the resample term.
+__global__ __launch_bounds__(256) void attn_gate_dgrad_kernel(const float *__restrict__ gpre,
+                                                              const float *__restrict__ params, int Ci, int Cx,
+                                                              int Cg, int Hg, int Wg, float *__restrict__ grad_x,
+                                                              float *__restrict__ grad_g, i64 cells) {
+  const int K = Cx + Cg;
+  const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const i64 cell = (i64)blockIdx.x * CELLS + lane;
+  if (cell >= cells) return;
+  const i64 hw = (i64)Hg * Wg;
+  const i64 n = cell / hw;
+  const int rem = (int)(cell - n * hw);
+  const int h = rem / Wg, w = rem - h * Wg;
+  const int per = (K + 3) / 4, k_begin = grp * per, k_end = min(K, k_begin + per);
+  const float *gp = gpre + n * Ci * hw + rem;
+  for (int k0 = k_begin; k0 < k_end; k0 += 8) {
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    for (int o = 0; o < Ci; ++o) {
+      const float v = gp[o * hw];
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (k0 + j < k_end) acc[j] = fmaf(v, params[(i64)(k0 + j) * Ci + o], acc[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = k0 + j;
+      if (k >= k_end) break;
+      if (k < Cx) {
+        const i64 idx = ((n * Cx + k) * (2 * Hg) + 2 * h) * (i64)(2 * Wg) + 2 * w;
+        grad_x[idx] += acc[j];
+      } else {
+        grad_g[((n * Cg + (k - Cx)) * Hg + h) * (i64)Wg + w] = acc[j];
+      }
+    }
+  }
+}
+
+// Weight gradient of the projections: dW[k][o] = sum_cells in[k] * gpre[o].  A workgroup owns a
+// 32(k) x 32(o) tile over a slice of the cells, staged 64 cells at a time through LDS; thread
+// (ti, to) accumulates a 2 x 2 sub-tile.  part[split][K][Ci].
+__global__ __launch_bounds__(256) void attn_wgrad_kernel(GateIn in, const float *__restrict__ gpre, int Ci,
+                                                         float *__restrict__ part, i64 cells, i64 cells_per_split) {
+  __shared__ float A[32][CELLS + 1], B[32][CELLS + 1];
+  const int K = in.Cx + in.Cg;
+  const int k0 = blockIdx.x * 32, o0 = blockIdx.y * 32, split = blockIdx.z;
+  const int ti = threadIdx.x & 15, to = threadIdx.x >> 4;
+  const i64 hw = (i64)in.Hg * in.Wg;
+  const i64 c_begin = split * cells_per_split, c_end = min(cells, c_begin + cells_per_split);
+  float acc[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+  for (i64 cb = c_begin; cb < c_end; cb += CELLS) {
+    for (int e = threadIdx.x; e < 32 * CELLS; e += 256) {
+      const int ch = e >> 6, cl = e & 63;
+      const i64 cell = cb + cl;
+      float a = 0.f, b = 0.f;
+      if (cell < c_end) {
+        const i64 n = cell / hw;
+        const int rem = (int)(cell - n * hw);
+        if (k0 + ch < K) {
+          const int h = rem / in.Wg, w = rem - h * in.Wg;
+          a = gate_input(in, k0 + ch, n, h, w);
+        }
+        if (o0 + ch < Ci) b = gpre[(n * Ci + o0 + ch) * hw + rem];
+      }
+      A[ch][cl] = a;
+      B[ch][cl] = b;
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int p = 0; p < CELLS; ++p) {
+      const float a0 = A[2 * ti][p], a1 = A[2 * ti + 1][p], b0 = B[2 * to][p], b1 = B[2 * to + 1][p];
+      acc[0][0] = fmaf(a0, b0, acc[0][0]);
+      acc[0][1] = fmaf(a0, b1, acc[0][1]);
+      acc[1][0] = fmaf(a1, b0, acc[1][0]);
+      acc[1][1] = fmaf(a1, b1, acc[1][1]);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int k = k0 + 2 * ti + i, o = o0 + 2 * to + j;
+      if (k < K && o < Ci) part[((i64)split * K + k) * Ci + o] = acc[i][j];
+    }
+}
+
+// grad[e] = sum_split part[split][e], splits in order
+__global__ __launch_bounds__(256) void attn_wgrad_reduce_kernel(const float *__restrict__ part, int splits, i64 count,
+                                                                float *__restrict__ grad) {
+  for (i64 e = (i64)blockIdx.x * blockDim.x + threadIdx.x; e < count; e += (i64)gridDim.x * blockDim.x) {
+    float t = 0.f;
+    for (int sidx = 0; sidx < splits; ++sidx) t += part[(i64)sidx * count + e];
+    grad[e] = t;
+  }
+}
+
+// The vector-shaped gradients, one workgroup each (block_sum: fixed order):
+//   blockIdx.x <  Ci : dpsi[o] = sum_cells gz * int1[o]   and   db1[o] = sum_cells gpre[o]
+//   blockIdx.x == Ci : dbpsi   = sum_cells gz,            gz = galpha * alpha * (1 - alpha)
+__global__ __launch_bounds__(256) void attn_vec_grad_kernel(const float *__restrict__ galpha,
+                                                            const float *__restrict__ alpha,
+                                                            const float *__restrict__ int1,
+                                                            const float *__restrict__ gpre, int Ci, i64 hw,
+                                                            i64 cells, float *__restrict__ grad_psi,
+                                                            float *__restrict__ grad_b1, float *__restrict__ grad_bpsi) {
+  __shared__ float red[2 * 4];
+  const int o = blockIdx.x;
+  float v[2] = {0.f, 0.f};
+  for (i64 cell = threadIdx.x; cell < cells; cell += 256) {
+    const float al = alpha[cell];
+    const float gz = galpha[cell] * al * (1.0f - al);
+    if (o < Ci) {
+      const i64 n = cell / hw;
+      const i64 idx = (n * Ci + o) * hw + (cell - n * hw);
+      v[0] = fmaf(gz, int1[idx], v[0]);
+      v[1] += gpre[idx];
+    } else {
+      v[0] += gz;
+    }
+  }
+  block_sum<2>(v, red);
+  if (threadIdx.x == 0) {
+    if (o < Ci) {
+      grad_psi[o] = v[0];
+      grad_b1[o] = v[1];
+    } else {
+      grad_bpsi[0] = v[0];
+    }
+  }
+}
+
+int check_attention_shape(const char *who, int batch, int H_x, int W_x, int Cx, int Cg, int Ci) {
+  UNET_REQUIRE(batch > 0 && H_x >= 2 && W_x >= 2 && H_x % 2 == 0 && W_x % 2 == 0 && Cx > 0 && Cg > 0 && Ci > 0,
+               "%s: need batch, channel counts > 0 and even H_x, W_x >= 2 (g is half the size of x)", who);
+  UNET_REQUIRE((i64)batch * H_x * W_x < ((i64)1 << 31), "%s: batch * H_x * W_x must stay below 2^31", who);
+  return UNET_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t unet_attention_param_count(int channels_in_x, int channels_in_g, int int_channels) {
+  return (int64_t)(channels_in_x + channels_in_g + 2) * int_channels + 1;
+}
+
+int unet_attention_f32(float *activations_int_1, float *activations_int_2, float *activations, const float *weights,
+                       const float *input_x, const float *input_g, int batch_size, int H_x, int W_x,
+                       int channels_in_x, int channels_in_g, int int_channels, unet_stream_t s) {
+  UNET_REQUIRE(activations_int_1 && activations_int_2 && activations && weights && input_x && input_g,
+               "unet_attention_f32: NULL pointer");
+  int rc = check_attention_shape("unet_attention_f32", batch_size, H_x, W_x, channels_in_x, channels_in_g, int_channels);
+  if (rc) return rc;
+  const int Hg = H_x / 2, Wg = W_x / 2;
+  const i64 cells = (i64)batch_size * Hg * Wg, pixels = 4 * cells;
+  const GateIn in{input_x, input_g, channels_in_x, channels_in_g, Hg, Wg};
+  hipLaunchKernelGGL(attn_gate_fwd_kernel, dim3(cdiv_u(cells, CELLS)), dim3(256), 0, as_stream(s), in, weights,
+                     int_channels, activations_int_1, activations_int_2, cells);
+  UNET_LAUNCH_CHECK("attn_gate_fwd_kernel");
+  hipLaunchKernelGGL(attn_resample_mul_kernel, dim3(ew_grid(pixels)), dim3(256), 0, as_stream(s), input_x,
+                     (const float *)activations_int_2, activations, channels_in_x, H_x, W_x, pixels);
+  UNET_LAUNCH_CHECK("attn_resample_mul_kernel");
+  return UNET_OK;
+}
+
+int unet_attention_backward_f32(const float *grad_activations, const float *activations_int_1,
+                                const float *activations_int_2, const float *input_x, const float *input_g,
+                                const float *weights, float *grad_activations_int_1, float *grad_activations_int_2,
+                                float *grad_input_x, float *grad_input_g, float *grad_weights, int batch_size, int H_x,
+                                int W_x, int channels_in_x, int channels_in_g, int int_channels, unet_stream_t s) {
+  UNET_REQUIRE(grad_activations && activations_int_1 && activations_int_2 && input_x && input_g && weights &&
+                   grad_activations_int_1 && grad_activations_int_2 && grad_input_x && grad_input_g && grad_weights,
+               "unet_attention_backward_f32: NULL pointer");
+  int rc = check_attention_shape("unet_attention_backward_f32", batch_size, H_x, W_x, channels_in_x, channels_in_g,
+                                 int_channels);
+  if (rc) return rc;
+  const int Cx = channels_in_x, Cg = channels_in_g, Ci = int_channels, K = Cx + Cg;
+  const int Hg = H_x / 2, Wg = W_x / 2;
+  const i64 cells = (i64)batch_size * Hg * Wg, pixels = 4 * cells;
+  // weight-gradient split over the cells: enough workgroups to fill the device when the tile count is small
+  const int tiles = (int)cdiv_u(K, 32) * (int)cdiv_u(Ci, 32);
+  i64 splits = (512 + tiles - 1) / tiles;
+  const i64 max_splits = (cells + 4 * CELLS - 1) / (4 * CELLS);
+  if (splits > max_splits) splits = max_splits;
+  if (splits > 1024) splits = 1024;
+  if (splits < 1) splits = 1;
+  i64 cells_per_split = (cells + splits - 1) / splits;
+  cells_per_split = (cells_per_split + CELLS - 1) / CELLS * CELLS;
+  splits = (cells + cells_per_split - 1) / cells_per_split;
+  // workspace: s [pixels] | weight-gradient partials [splits][K][Ci]
+  const size_t s_floats = (size_t)pixels, part_floats = (size_t)splits * K * Ci;
+  void *ws;
+  rc = unet_workspace(&ws, sizeof(float) * (s_floats + part_floats), as_stream(s));
+  if (rc) return rc;
+  float *sbuf = (float *)ws, *part = sbuf + s_floats;
+  const float *psi = weights + (i64)K * Ci;
+  float *grad_psi = grad_weights + (i64)K * Ci, *grad_b1 = grad_psi + Ci, *grad_bpsi = grad_b1 + Ci;
+  const GateIn in{input_x, input_g, Cx, Cg, Hg, Wg};
+
+  hipLaunchKernelGGL(attn_resample_bwd_kernel, dim3(ew_grid(pixels)), dim3(256), 0, as_stream(s), grad_activations,
+                     input_x, activations_int_2, grad_input_x, sbuf, Cx, H_x, W_x, pixels);
+  UNET_LAUNCH_CHECK("attn_resample_bwd_kernel");
+  hipLaunchKernelGGL(attn_cell_bwd_kernel, dim3(ew_grid(cells)), dim3(256), 0, as_stream(s), (const float *)sbuf,
+                     activations_int_2, activations_int_1, psi, grad_activations_int_2, grad_activations_int_1, Ci,
+                     H_x, W_x, cells);
+  UNET_LAUNCH_CHECK("attn_cell_bwd_kernel");
+  hipLaunchKernelGGL(attn_gate_dgrad_kernel, dim3(cdiv_u(cells, CELLS)), dim3(256), 0, as_stream(s),
+                     (const float *)grad_activations_int_1, weights, Ci, Cx, Cg, Hg, Wg, grad_input_x, grad_input_g,
+                     cells);
+  UNET_LAUNCH_CHECK("attn_gate_dgrad_kernel");
+  hipLaunchKernelGGL(attn_wgrad_kernel, dim3(cdiv_u(K, 32), cdiv_u(Ci, 32), (unsigned)splits), dim3(256), 0,
+                     as_stream(s), in, (const float *)grad_activations_int_1, Ci, part, cells, cells_per_split);
+  UNET_LAUNCH_CHECK("attn_wgrad_kernel");
+  hipLaunchKernelGGL(attn_wgrad_reduce_kernel, dim3(ew_grid((i64)K * Ci)), dim3(256), 0, as_stream(s),
+                     (const float *)part, (int)splits, (i64)K * Ci, grad_weights);
+  UNET_LAUNCH_CHECK("attn_wgrad_reduce_kernel");
+  hipLaunchKernelGGL(attn_vec_grad_kernel, dim3(Ci + 1), dim3(256), 0, as_stream(s),
+                     (const float *)grad_activations_int_2, activations_int_2, activations_int_1,
+                     (const float *)grad_activations_int_1, Ci, (i64)Hg * Wg, cells, grad_psi, grad_b1, grad_bpsi);
+  UNET_LAUNCH_CHECK("attn_vec_grad_kernel");
+  return UNET_OK;
+}
+
+}  // extern "C"
