@@ -204,7 +204,7 @@ int unet_max_pool_backward_indices_f32(const float *grad_activations, const int3
  * into zeroed buffers with atomicAdd); every sum has a fixed order.  In the backward,
  * grad_activations_int_1 receives the gradient at the ReLU input and grad_activations_int_2
  * the gradient of int_2; grad_input_x includes the stride-2 projection's term. */
-int64_t unet_attention_param_count(int channels_in_x, int channels_in_g, int int_channels);
+int unet_attention_param_count(int channels_in_x, int channels_in_g, int int_channels);
 int unet_attention_f32(float *activations_int_1, float *activations_int_2, float *activations,
                        const float *weights, const float *input_x, const float *input_g,
                        int batch_size, int H_x, int W_x, int channels_in_x, int channels_in_g,

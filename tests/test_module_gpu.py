@@ -115,8 +115,7 @@ def test_create_validation_messages(nn):
         nn.NeuralNet().create([L(T.CONV_LAYER, [8, 8, 3, 4, 3, 1, 1], []), L(T.CONV_LAYER, [8, 8, 4, 4, 3, 1, 1], [0]),
                                L(T.CONV_LAYER, [8, 8, 4, 4, 3, 1, 1], [0, 1])], nn.DICE_LOSS)
     with pytest.raises(RuntimeError, match="not implemented"):
-        nn.NeuralNet().create([L(T.CONV_LAYER, [8, 8, 3, 4, 3, 1, 1], []), L(T.ATTENTION_LAYER, [], [0, 0])],
-                              nn.DICE_LOSS)
+        nn.NeuralNet().create([L(T.CONV_LAYER, [8, 8, 3, 4, 3, 1, 1], []), L(T.FC_LAYER, [], [0])], nn.DICE_LOSS)
     net = nn.NeuralNet()
     with pytest.raises(RuntimeError, match="create"):
         net.train(np.zeros((1, 3, 8, 8), np.float32), np.zeros((1, 8, 8), np.float32), 1e-3, 1, 1)

@@ -76,9 +76,93 @@ def unet_graph(h=256, w=256, cin=3, base=64, depth=4, double_conv=True):
     return g
 
 
+def attention_unet_graph(h=64, w=64, cin=3, f1=8):
+    """The "Attention U-Net" graph the reference keeps commented out in main.py:144-184: the main.py
+    graph with an attention gate on every skip connection (x = the encoder output, g = the decoder
+    tensor one level below, before upsampling)."""
+    f2, f3, f4 = 2 * f1, 4 * f1, 8 * f1
+    h2, h3, h4, w2, w3, w4 = h // 2, h // 4, h // 8, w // 2, w // 4, w // 8
+    return [
+        ("conv", [h, w, cin, f1, 3, 1, 1], [], "relu"),      # 0
+        ("pool", [f1, h, w, 2, 2], [0], None),               # 1
+        ("conv", [h2, w2, f1, f2, 3, 1, 1], [1], "relu"),    # 2
+        ("pool", [f2, h2, w2, 2, 2], [2], None),             # 3
+        ("conv", [h3, w3, f2, f3, 3, 1, 1], [3], "relu"),    # 4
+        ("pool", [f3, h3, w3, 2, 2], [4], None),             # 5
+        ("conv", [h4, w4, f3, f4, 3, 1, 1], [5], "relu"),    # 6
+        ("up", [h4, w4, f4, f3, 2], [6], None),              # 7
+        ("attention", [], [4, 6], None),                     # 8
+        ("concat", [], [8, 7], None),                        # 9
+        ("conv", [h3, w3, f4, f2, 3, 1, 1], [9], "relu"),    # 10
+        ("up", [h3, w3, f2, f2, 2], [10], None),             # 11
+        ("attention", [], [2, 10], None),                    # 12
+        ("concat", [], [12, 11], None),                      # 13
+        ("conv", [h2, w2, f3, f1, 3, 1, 1], [13], "relu"),   # 14
+        ("up", [h2, w2, f1, f1, 2], [14], None),             # 15
+        ("attention", [], [0, 14], None),                    # 16
+        ("concat", [], [16, 15], None),                      # 17
+        ("conv", [h, w, f2, 1, 3, 1, 1], [17], "sigmoid"),   # 18
+    ]
+
+
+def out_channels(graph):
+    """Output channel count of every layer."""
+    c = []
+    for kind, s, parents, _ in graph:
+        if kind in ("conv", "up"):
+            c.append(s[3])
+        elif kind == "pool":
+            c.append(s[0])
+        elif kind == "concat":
+            c.append(c[parents[0]] + c[parents[1]])
+        elif kind == "attention":
+            c.append(c[parents[0]])
+        else:
+            raise ValueError(kind)
+    return c
+
+
+def attention_dims(graph, i):
+    """(Cx, Cg, Ci) of attention layer i: Ci = Cx / 2 (attention_layer_functions.h:18)."""
+    c = out_channels(graph)
+    cx, cg = c[graph[i][2][0]], c[graph[i][2][1]]
+    return cx, cg, cx // 2
+
+
+def attention_gate(x, g, flat, ci):
+    """The reference's attention gate (src/cuda_library/attention/attention.cu:9-203) with torch operators;
+    flat = W[(Cx+Cg)][Ci] | psi[Ci] | b1[Ci] | bpsi (layer.h:558-566).  The blend back to the resolution of
+    x mixes, per 4x4 block of output pixels, the 2x2 coefficient cells at (2*(h//4), 2*(w//4)) with
+    fractions (h%4)/3, (w%4)/3 (:61-78), the "+1" cells clamped to the last row / column (:65-66)."""
+    n, cx, hx, wx = x.shape
+    cg = g.shape[1]
+    W = flat[:(cx + cg) * ci].view(cx + cg, ci)
+    psi = flat[(cx + cg) * ci:(cx + cg + 1) * ci]
+    b1 = flat[(cx + cg + 1) * ci:(cx + cg + 2) * ci]
+    bpsi = flat[(cx + cg + 2) * ci]
+    int1 = F.relu(F.conv2d(x, W[:cx].t().reshape(ci, cx, 1, 1), stride=2) +
+                  F.conv2d(g, W[cx:].t().reshape(ci, cg, 1, 1)) + b1.view(1, -1, 1, 1))
+    alpha = torch.sigmoid((int1 * psi.view(1, -1, 1, 1)).sum(1) + bpsi)
+
+    def axis(n_out, n_cells):
+        i = torch.arange(n_out)
+        c0 = (i // 2) // 2 * 2
+        c1 = torch.clamp(c0 + 1, max=n_cells - 1)
+        frac = ((i % 4).to(torch.float32) / torch.tensor(3.0, dtype=torch.float32)).to(x.dtype)
+        return c0, c1, frac
+
+    h0, h1, fh = axis(hx, hx // 2)
+    w0, w1, fw = axis(wx, wx // 2)
+    A, B = alpha[:, h0][:, :, w0], alpha[:, h0][:, :, w1]
+    C, D = alpha[:, h1][:, :, w0], alpha[:, h1][:, :, w1]
+    interp = (D * fw + C * (1 - fw)) * fh[:, None] + (B * fw + A * (1 - fw)) * (1 - fh[:, None])
+    return x * interp[:, None]
+
+
 def to_layer_descs(nn, graph):
     kinds = {"conv": nn.LayerType.CONV_LAYER, "pool": nn.LayerType.MAX_POOL_LAYER,
-             "up": nn.LayerType.UPSAMPLING_LAYER, "concat": nn.LayerType.CONCAT_LAYER}
+             "up": nn.LayerType.UPSAMPLING_LAYER, "concat": nn.LayerType.CONCAT_LAYER,
+             "attention": nn.LayerType.ATTENTION_LAYER}
     out = []
     for kind, shape, parents, act in graph:
         if act == "sigmoid":
@@ -95,6 +179,10 @@ def param_count(graph):
             n += s[2] * s[3] * s[4] * s[4] + s[3] + 2 * s[3]
         elif kind == "up":
             n += s[2] * s[3] * s[4] * s[4] + s[3] + 2 * s[3]
+    for i, layer in enumerate(graph):
+        if layer[0] == "attention":
+            cx, cg, ci = attention_dims(graph, i)
+            n += (cx + cg + 2) * ci + 1
     return n
 
 
@@ -102,8 +190,13 @@ def split_params(graph, flat):
     """-> list (per layer) of dicts of torch leaf tensors (float64, requires_grad) or None."""
     flat = torch.as_tensor(np.asarray(flat, dtype=np.float64))
     out, off = [], 0
-    for kind, s, _, _ in graph:
-        if kind in ("conv", "up"):
+    for i, (kind, s, _, _) in enumerate(graph):
+        if kind == "attention":
+            cx, cg, ci = attention_dims(graph, i)
+            cnt = (cx + cg + 2) * ci + 1
+            out.append({"att": flat[off:off + cnt].clone().requires_grad_(True)})
+            off += cnt
+        elif kind in ("conv", "up"):
             ci, co, k = s[2], s[3], s[4]
             nw = ci * co * k * k
             d = {
@@ -124,6 +217,9 @@ def flat_grads(graph, params):
     parts = []
     for p in params:
         if p is None:
+            continue
+        if "att" in p:
+            parts.append(p["att"].grad.reshape(-1))
             continue
         parts += [p["w"].grad.reshape(-1), p["b"].grad.reshape(-1),
                   torch.stack([p["gamma"].grad, p["beta"].grad], dim=1).reshape(-1)]
@@ -214,6 +310,9 @@ def forward(graph, params, x, training=True, running=None, emulate_bf16=False):
             acts.append(_MaxPoolTies.apply(inp, s[3]) if emulate_bf16 else F.max_pool2d(inp, s[3], s[4]))
         elif kind == "concat":
             acts.append(torch.cat([acts[parents[0]], acts[parents[1]]], dim=1))
+        elif kind == "attention":
+            acts.append(attention_gate(acts[parents[0]], acts[parents[1]], params[i]["att"],
+                                       attention_dims(graph, i)[2]))
         else:
             raise ValueError(kind)
     return acts

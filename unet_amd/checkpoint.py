@@ -88,13 +88,50 @@ def layer_from_torch(weight, bias, transposed):
     return np.concatenate([np.ascontiguousarray(w).reshape(-1), np.asarray(bias, dtype=np.float32).reshape(-1)])
 
 
+ATTENTION_KEYS = ("w_x.weight", "w_g.weight", "w_g.bias", "psi.weight", "psi.bias")
+
+
+def attention_to_torch(flat, c_x, c_g):
+    """Attention-gate parameters W[(Cx+Cg)][Ci] | psi[Ci] | b1[Ci] | bpsi -> the tensors of the usual PyTorch
+    attention gate: w_x = Conv2d(Cx, Ci, 1, stride=2, bias=False), w_g = Conv2d(Cg, Ci, 1), psi = Conv2d(Ci, 1, 1)."""
+    flat = np.asarray(flat, dtype=np.float32)
+    ci = (flat.size - 1) // (c_x + c_g + 2)
+    if (c_x + c_g + 2) * ci + 1 != flat.size:
+        raise RuntimeError(f"attention gate: {flat.size} parameters do not fit Cx={c_x}, Cg={c_g}")
+    w = flat[:(c_x + c_g) * ci].reshape(c_x + c_g, ci)
+    k = (c_x + c_g) * ci
+    return {"w_x.weight": np.ascontiguousarray(w[:c_x].T).reshape(ci, c_x, 1, 1),
+            "w_g.weight": np.ascontiguousarray(w[c_x:].T).reshape(ci, c_g, 1, 1),
+            "w_g.bias": flat[k + ci:k + 2 * ci].copy(),
+            "psi.weight": flat[k:k + ci].reshape(1, ci, 1, 1).copy(),
+            "psi.bias": flat[k + 2 * ci:k + 2 * ci + 1].copy()}
+
+
+def attention_from_torch(t):
+    """Inverse of attention_to_torch()."""
+    wx, wg = np.asarray(t["w_x.weight"], np.float32), np.asarray(t["w_g.weight"], np.float32)
+    ci = wx.shape[0]
+    w = np.concatenate([wx.reshape(ci, -1).T, wg.reshape(ci, -1).T], axis=0)
+    return np.concatenate([w.reshape(-1), np.asarray(t["psi.weight"], np.float32).reshape(-1),
+                           np.asarray(t["w_g.bias"], np.float32).reshape(-1),
+                           np.asarray(t["psi.bias"], np.float32).reshape(-1)])
+
+
 def to_torch(net, descs):
     """descs: the LayerDesc list the network was created from.  Returns numpy arrays keyed like a
     PyTorch state_dict: layers.<i>.conv.{weight,bias}, layers.<i>.bn.{weight,bias,running_mean,running_var}."""
     flat = np.asarray(net.get_parameters(), dtype=np.float32)
     parts = split_parameters(flat, net.parameter_layout())
     out = {}
+    shapes = net.output_shapes()
+    for i, off, nwb, nbn in net.parameter_layout():
+        if nbn == 0:                            # attention gate: parents = [x, g]
+            cx, cg = (shapes[p][0] for p in descs[i].parents)
+            for key, v in attention_to_torch(flat[off:off + nwb], cx, cg).items():
+                out[f"layers.{i}.{key}"] = v
     for i, p in parts.items():
+        if p["gamma"].size == 0:
+            continue
         shape = list(descs[i].shape)
         transposed = len(shape) == 5            # UPSAMPLING: [H, W, C_in, C_out, scale]
         c_in, c_out, k = shape[2], shape[3], shape[4]
@@ -115,6 +152,12 @@ def from_torch(net, descs, state):
         return v.detach().cpu().numpy() if hasattr(v, "detach") else np.asarray(v)
     flat = np.asarray(net.get_parameters(), dtype=np.float32).copy()
     for i, off, nwb, nbn in net.parameter_layout():
+        if nbn == 0:                            # attention gate
+            wb = attention_from_torch({k: arr(state[f"layers.{i}.{k}"]) for k in ATTENTION_KEYS})
+            if wb.size != nwb:
+                raise RuntimeError(f"layer {i}: expected {nwb} attention parameters, got {wb.size}")
+            flat[off:off + nwb] = wb
+            continue
         shape = list(descs[i].shape)
         transposed = len(shape) == 5
         wb = layer_from_torch(arr(state[f"layers.{i}.conv.weight"]), arr(state[f"layers.{i}.conv.bias"]), transposed)

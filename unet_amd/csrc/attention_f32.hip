@@ -353,8 +353,8 @@ int check_attention_shape(const char *who, int batch, int H_x, int W_x, int Cx, 
 
 extern "C" {
 
-int64_t unet_attention_param_count(int channels_in_x, int channels_in_g, int int_channels) {
-  return (int64_t)(channels_in_x + channels_in_g + 2) * int_channels + 1;
+int unet_attention_param_count(int channels_in_x, int channels_in_g, int int_channels) {
+  return (channels_in_x + channels_in_g + 2) * int_channels + 1;
 }
 
 int unet_attention_f32(float *activations_int_1, float *activations_int_2, float *activations, const float *weights,

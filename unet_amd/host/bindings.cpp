@@ -199,7 +199,7 @@ class NN {
     std::vector<std::tuple<int, int64_t, int64_t, int64_t>> out;
     for (size_t i = 0; i < net_.nodes().size(); ++i) {
       const unet::Node &n = net_.nodes()[i];
-      if (n.has_params()) out.emplace_back((int)i, n.param_off, n.num_wb, n.num_bn);
+      if (n.num_wb + n.num_bn > 0) out.emplace_back((int)i, n.param_off, n.num_wb, n.num_bn);
     }
     return out;
   }

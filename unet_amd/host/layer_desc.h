@@ -26,6 +26,7 @@ enum class LossFunction {
 //   MAX_POOL_LAYER    [C, H, W, kernel, stride]
 //   UPSAMPLING_LAYER  [H_in, W_in, C_in, C_out, scale]
 //   CONCAT_LAYER      []   (shape from the two parents; first parent = skip)
+//   ATTENTION_LAYER   []   (parents = [x (skip), g (gating, half the size of x)]; layer.h:521-571)
 struct LayerDesc {
   Layer_type type;
   std::vector<int> descriptor;

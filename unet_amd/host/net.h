@@ -133,7 +133,8 @@ struct Node {
   const Node *pool_src = nullptr;  // (backward) the pool whose gradient this layer still has to gather
   int64_t in_elems() const { return (int64_t)in_c * in_h * in_w; }
   int64_t out_elems() const { return (int64_t)out_c * out_h * out_w; }
-  bool has_params() const { return type == CONV_LAYER || type == UPSAMPLING_LAYER; }
+  bool has_params() const { return type == CONV_LAYER || type == UPSAMPLING_LAYER; }  // weights + batch norm
+  int att_ci() const { return in_c / 2; }  // attention gate: intermediate channels (attention_layer_functions.h:18)
 };
 
 class Net {
@@ -207,7 +208,7 @@ class Net {
     init_parameters(seed_);
     if (verbose_)
       for (const Node &n : nodes_)
-        if (n.has_params()) std::cout << "add params: " << n.num_wb + n.num_bn << std::endl;
+        if (n.num_wb + n.num_bn > 0) std::cout << "add params: " << n.num_wb + n.num_bn << std::endl;
     // compute path: bf16 NHWC on the matrix cores when the graph allows it
     const char *want = std::getenv("UNET_DTYPE");
     const bool want_bf16 = !want || std::string(want) != "fp32";
@@ -229,6 +230,13 @@ class Net {
     uint64_t layer_id = 0;
     for (Node &n : nodes_) {
       ++layer_id;
+      if (n.type == ATTENTION_LAYER) {
+        // projection and psi weights He-initialised, the Ci + 1 biases zero (layer.h:562-569 passes the weight
+        // count as the fan; the fan-in of the additive projection is used here)
+        UNET_CALL(unet_init_he_f32(params_.f32() + n.param_off, n.num_wb - (n.att_ci() + 1), n.fan,
+                                   seed * 1000003ull + layer_id, stream_));
+        continue;
+      }
       if (!n.has_params()) continue;
       float *w = params_.f32() + n.param_off;
       UNET_CALL(unet_init_he_f32(w, n.num_wb - n.out_c, n.fan, seed * 1000003ull + layer_id, stream_));
@@ -570,6 +578,12 @@ class Net {
       n.grad_out.ensure(out_bytes);
       max_out = std::max(max_out, n.out_elems());
       int64_t in_e = n.type == CONCAT_LAYER ? n.out_elems() : n.in_elems();
+      if (n.type == ATTENTION_LAYER) {
+        const size_t cells = b * (size_t)(n.in_h / 2) * (n.in_w / 2);
+        n.z.ensure(sizeof(float) * cells * n.att_ci());  // int_1: the ReLU output of the additive projection
+        n.bn.ensure(sizeof(float) * cells);              // int_2: the attention coefficients
+        in_e = n.in_elems() + (int64_t)n.c2 * (n.in_h / 2) * (n.in_w / 2);  // gradients of x and g side by side
+      }
       max_in = std::max(max_in, in_e);
     }
     scratch_g1_.ensure(sizeof(float) * b * (size_t)max_out);
@@ -689,8 +703,31 @@ class Net {
         n.fan = (int64_t)n.in_c;  // each output pixel sums C_in products
         break;
       }
-      case ATTENTION_LAYER:
-        throw std::runtime_error("ATTENTION_LAYER is not implemented in this build");
+      case ATTENTION_LAYER: {
+        // layer.h:521-571: parents = (x, g), g half the size of x; the descriptor carries no shape
+        if (n.parents.size() != 2) {
+          std::stringstream ss;
+          ss << "Attention layers need two parents: " << n.parents.size() << " parents givent";
+          throw std::runtime_error(ss.str());
+        }
+        const Node &x = parent(0), &g = parent(1);
+        if (g.out_h != x.out_h / 2 || g.out_w != x.out_w / 2 || x.out_h % 2 != 0 || x.out_w % 2 != 0) {
+          std::stringstream ss;
+          ss << "attention not implemented for g that is not half the size of x. g dimensions: " << g.out_h << ", "
+             << g.out_w << std::endl
+             << "x dimensions: " << x.out_h << ", " << x.out_w;
+          throw std::runtime_error(ss.str());
+        }
+        if (x.out_c < 2) throw std::runtime_error("attention layer: x needs at least two channels");
+        n.c1 = x.out_c; n.c2 = g.out_c;
+        n.in_c = x.out_c; n.in_h = x.out_h; n.in_w = x.out_w;
+        n.out_c = n.in_c; n.out_h = n.in_h; n.out_w = n.in_w;
+        n.input_shape = {x.out_c, x.out_h, x.out_w, g.out_c, g.out_h, g.out_w};
+        n.num_wb = unet_attention_param_count(n.c1, n.c2, n.att_ci());
+        n.num_bn = 0;
+        n.fan = (int64_t)n.c1 + n.c2;
+        break;
+      }
       case BN_LAYER:
         throw std::runtime_error("BN_LAYER is not implemented (batch norm is part of CONV and UPSAMPLING layers)");
       case FC_LAYER:
@@ -751,6 +788,11 @@ class Net {
       case CONCAT_LAYER:
         UNET_CALL(unet_concat_f32(nodes_[n.parents[0]].act.f32(), nodes_[n.parents[1]].act.f32(), n.act.f32(), batch,
                                   (int64_t)n.in_h * n.in_w, n.c1, n.c2, stream_));
+        break;
+      case ATTENTION_LAYER:  // attention_layer_functions.h:4-28
+        UNET_CALL(unet_attention_f32(n.z.f32(), n.bn.f32(), n.act.f32(), params_.f32() + n.param_off,
+                                     nodes_[n.parents[0]].act.f32(), nodes_[n.parents[1]].act.f32(), batch, n.in_h,
+                                     n.in_w, n.c1, n.c2, n.att_ci(), stream_));
         break;
       default:
         throw std::runtime_error("unsupported layer type in forward");
@@ -813,6 +855,18 @@ class Net {
         Node &a = nodes_[n.parents[0]], &b = nodes_[n.parents[1]];
         commit_copy(a, tmp, n1);
         commit_copy(b, tmp + n1, n2);
+        break;
+      }
+      case ATTENTION_LAYER: {  // attention_layer_functions.h:30-58: dLdX holds the x gradient, then the g gradient
+        Node &x = nodes_[n.parents[0]], &g = nodes_[n.parents[1]];
+        const int64_t n1 = (int64_t)batch * x.out_elems(), n2 = (int64_t)batch * g.out_elems();
+        float *tmp = scratch_dx_.f32();
+        UNET_CALL(unet_attention_backward_f32(n.grad_out.f32(), n.z.f32(), n.bn.f32(), x.act.f32(), g.act.f32(),
+                                              params_.f32() + n.param_off, scratch_g1_.f32(), scratch_g2_.f32(), tmp,
+                                              tmp + n1, grads_.f32() + n.param_off, batch, n.in_h, n.in_w, n.c1, n.c2,
+                                              n.att_ci(), stream_));
+        commit_copy(x, tmp, n1);
+        commit_copy(g, tmp + n1, n2);
         break;
       }
       default:
