@@ -49,18 +49,40 @@ __device__ __forceinline__ float gate_input(const GateIn &in, int k, i64 n, int 
   if (k < in.Cx) return in.x[((n * in.Cx + k) * (2 * in.Hg) + 2 * h) * (i64)(2 * in.Wg) + 2 * w];
   return in.g[((n * in.Cg + (k - in.Cx)) * in.Hg + h) * (i64)in.Wg + w];
 }
+// The same through two per-cell base pointers: channel k is one plane stride further.
+struct GateCell {
+  const float *xp, *gp;
+  i64 xplane, gplane;
+  int Cx;
+};
+__device__ __forceinline__ GateCell gate_cell(const GateIn &in, i64 n, int h, int w) {
+  GateCell c;
+  c.gplane = (i64)in.Hg * in.Wg;
+  c.xplane = 4 * c.gplane;
+  c.xp = in.x + n * in.Cx * c.xplane + (i64)(2 * h) * (2 * in.Wg) + 2 * w;
+  c.gp = in.g + n * in.Cg * c.gplane + (i64)h * in.Wg + w;
+  c.Cx = in.Cx;
+  return c;
+}
+__device__ __forceinline__ float gate_input(const GateCell &c, int k) {
+  return k < c.Cx ? c.xp[k * c.xplane] : c.gp[(k - c.Cx) * c.gplane];
+}
 
 // ---- forward ---------------------------------------------------------------------------------
 // 256 threads = 64 consecutive cells x 4 channel groups; a thread walks its group's intermediate
 // channels eight at a time (the weights of a group are uniform over a wavefront).  The psi dot
 // product is summed over the four groups through LDS in group order.
+// FULL: every group has a multiple of eight channels and K is a multiple of eight, so the loops carry no
+// bounds tests (with them the compiler emits a branch per channel and trip).
+template <bool FULL>
 __global__ __launch_bounds__(256) void attn_gate_fwd_kernel(GateIn in, const float *__restrict__ params, int Ci,
                                                             float *__restrict__ int1, float *__restrict__ alpha,
                                                             i64 cells) {
   __shared__ float zpart[4][CELLS];
   const int K = in.Cx + in.Cg;
   const float *psi = params + (i64)K * Ci, *b1 = psi + Ci;
-  const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  // the channel group is the wavefront index: read it as a scalar so that the weight addresses are uniform
+  const int lane = threadIdx.x & 63, grp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const i64 cell = (i64)blockIdx.x * CELLS + lane;
   const bool live = cell < cells;
   const i64 hw = (i64)in.Hg * in.Wg;
@@ -68,21 +90,29 @@ __global__ __launch_bounds__(256) void attn_gate_fwd_kernel(GateIn in, const flo
   const int rem = live ? (int)(cell - n * hw) : 0;
   const int h = rem / in.Wg, w = rem - h * in.Wg;
   const int per = (Ci + 3) / 4, o_begin = grp * per, o_end = min(Ci, o_begin + per);
+  const GateCell gc = gate_cell(in, n, h, w);
   float z = 0.f;
   for (int o0 = o_begin; o0 < o_end; o0 += 8) {
     float acc[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc[j] = (o0 + j < o_end) ? b1[o0 + j] : 0.f;
-    for (int k = 0; k < K; ++k) {
-      const float v = live ? gate_input(in, k, n, h, w) : 0.f;
-      const float *wr = params + (i64)k * Ci + o0;
+    for (int j = 0; j < 8; ++j) acc[j] = (FULL || o0 + j < o_end) ? b1[o0 + j] : 0.f;
+    // eight input channels per trip: their loads are in flight together (x and g planes are hw apart)
+    for (int kb = 0; kb < K; kb += 8) {
+      float v[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j)
-        if (o0 + j < o_end) acc[j] = fmaf(v, wr[j], acc[j]);
+      for (int u = 0; u < 8; ++u) v[u] = (live && (FULL || kb + u < K)) ? gate_input(gc, kb + u) : 0.f;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (!FULL && kb + u >= K) break;
+        const float *wr = params + (i64)(kb + u) * Ci + o0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          if (FULL || o0 + j < o_end) acc[j] = fmaf(v[u], wr[j], acc[j]);
+      }
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j)
-      if (o0 + j < o_end) {
+      if (FULL || o0 + j < o_end) {
         const float r = acc[j] > 0.f ? acc[j] : 0.f;
         if (live) int1[(n * Ci + o0 + j) * hw + rem] = r;
         z = fmaf(r, psi[o0 + j], z);
@@ -210,12 +240,14 @@ __global__ __launch_bounds__(256) void attn_cell_bwd_kernel(const float *__restr
 // Input gradients of the two 1x1 projections: dst[k] (+)= sum_o gpre[o] * W[k][o] per cell.
 // Same thread layout as the forward: 64 cells x 4 groups of input channels, eight at a time.
 // The x part lands on the even pixels of grad_x, which already holds the resample term.
+// FULL: every group has a multiple of eight input channels and Ci is a multiple of eight.
+template <bool FULL>
 __global__ __launch_bounds__(256) void attn_gate_dgrad_kernel(const float *__restrict__ gpre,
                                                               const float *__restrict__ params, int Ci, int Cx,
                                                               int Cg, int Hg, int Wg, float *__restrict__ grad_x,
                                                               float *__restrict__ grad_g, i64 cells) {
   const int K = Cx + Cg;
-  const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, grp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const i64 cell = (i64)blockIdx.x * CELLS + lane;
   if (cell >= cells) return;
   const i64 hw = (i64)Hg * Wg;
@@ -228,16 +260,22 @@ __global__ __launch_bounds__(256) void attn_gate_dgrad_kernel(const float *__res
     float acc[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-    for (int o = 0; o < Ci; ++o) {
-      const float v = gp[o * hw];
+    for (int ob = 0; ob < Ci; ob += 8) {
+      float v[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j)
-        if (k0 + j < k_end) acc[j] = fmaf(v, params[(i64)(k0 + j) * Ci + o], acc[j]);
+      for (int u = 0; u < 8; ++u) v[u] = (FULL || ob + u < Ci) ? gp[(ob + u) * hw] : 0.f;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (!FULL && ob + u >= Ci) break;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          if (FULL || k0 + j < k_end) acc[j] = fmaf(v[u], params[(i64)(k0 + j) * Ci + ob + u], acc[j]);
+      }
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int k = k0 + j;
-      if (k >= k_end) break;
+      if (!FULL && k >= k_end) break;
       if (k < Cx) {
         const i64 idx = ((n * Cx + k) * (2 * Hg) + 2 * h) * (i64)(2 * Wg) + 2 * w;
         grad_x[idx] += acc[j];
@@ -248,53 +286,71 @@ __global__ __launch_bounds__(256) void attn_gate_dgrad_kernel(const float *__res
   }
 }
 
-// Weight gradient of the projections: dW[k][o] = sum_cells in[k] * gpre[o].  A workgroup owns a
-// 32(k) x 32(o) tile over a slice of the cells, staged 64 cells at a time through LDS; thread
-// (ti, to) accumulates a 2 x 2 sub-tile.  part[split][K][Ci].
+// Weight gradient of the projections: dW[k][o] = sum_cells in[k] * gpre[o], a GEMM whose reduction runs
+// over the cells.  A workgroup owns a 32(k) x 32(o) tile over a slice of the cells, staged 64 cells at a
+// time through LDS; each of its four wavefronts multiplies a quarter of the staged cells with
+// v_mfma_f32_32x32x2_f32 (fp32 operands and accumulator) and the four accumulators are added in
+// wavefront order at the end.  part[split][K][Ci].
+typedef float floatx16 __attribute__((ext_vector_type(16)));
 __global__ __launch_bounds__(256) void attn_wgrad_kernel(GateIn in, const float *__restrict__ gpre, int Ci,
                                                          float *__restrict__ part, i64 cells, i64 cells_per_split) {
-  __shared__ float A[32][CELLS + 1], B[32][CELLS + 1];
+  constexpr int PITCH = CELLS + 1;
+  __shared__ float sm[2 * 32 * PITCH];  // A[32][PITCH] (inputs), B[32][PITCH] (gpre); reused for the final sum
+  float *A = sm, *B = sm + 32 * PITCH;
   const int K = in.Cx + in.Cg;
   const int k0 = blockIdx.x * 32, o0 = blockIdx.y * 32, split = blockIdx.z;
-  const int ti = threadIdx.x & 15, to = threadIdx.x >> 4;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const i64 hw = (i64)in.Hg * in.Wg;
   const i64 c_begin = split * cells_per_split, c_end = min(cells, c_begin + cells_per_split);
-  float acc[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+  floatx16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
   for (i64 cb = c_begin; cb < c_end; cb += CELLS) {
-    for (int e = threadIdx.x; e < 32 * CELLS; e += 256) {
-      const int ch = e >> 6, cl = e & 63;
+    {
+      // thread t stages cell t % 64 of the chunk for the eight channels t / 64 + 4 i: one index
+      // computation per chunk, sixteen loads in flight
+      const int cl = lane;
       const i64 cell = cb + cl;
-      float a = 0.f, b = 0.f;
-      if (cell < c_end) {
-        const i64 n = cell / hw;
-        const int rem = (int)(cell - n * hw);
-        if (k0 + ch < K) {
-          const int h = rem / in.Wg, w = rem - h * in.Wg;
-          a = gate_input(in, k0 + ch, n, h, w);
-        }
-        if (o0 + ch < Ci) b = gpre[(n * Ci + o0 + ch) * hw + rem];
+      const bool in_range = cell < c_end;
+      const unsigned ucell = in_range ? (unsigned)cell : 0u;  // cells < 2^31 (checked by the caller)
+      const unsigned n = ucell / (unsigned)hw, rem = ucell - n * (unsigned)hw;
+      const int h = (int)(rem / (unsigned)in.Wg), w = (int)(rem - (unsigned)h * (unsigned)in.Wg);
+      const GateCell gc = gate_cell(in, n, h, w);
+      float a[8], b[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int ch = wave + 4 * i;
+        a[i] = (in_range && k0 + ch < K) ? gate_input(gc, k0 + ch) : 0.f;
+        b[i] = (in_range && o0 + ch < Ci) ? gpre[((i64)n * Ci + o0 + ch) * hw + rem] : 0.f;
       }
-      A[ch][cl] = a;
-      B[ch][cl] = b;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        A[(wave + 4 * i) * PITCH + cl] = a[i];
+        B[(wave + 4 * i) * PITCH + cl] = b[i];
+      }
     }
     __syncthreads();
-#pragma unroll 8
-    for (int p = 0; p < CELLS; ++p) {
-      const float a0 = A[2 * ti][p], a1 = A[2 * ti + 1][p], b0 = B[2 * to][p], b1 = B[2 * to + 1][p];
-      acc[0][0] = fmaf(a0, b0, acc[0][0]);
-      acc[0][1] = fmaf(a0, b1, acc[0][1]);
-      acc[1][0] = fmaf(a1, b0, acc[1][0]);
-      acc[1][1] = fmaf(a1, b1, acc[1][1]);
+    // lane l supplies A[row l%32][cell] and B[row l%32][cell] of cell 2q + l/32 of this wavefront's sixteen
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int cl = wave * 16 + 2 * q + (lane >> 5);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[(lane & 31) * PITCH + cl], B[(lane & 31) * PITCH + cl], acc, 0, 0, 0);
     }
     __syncthreads();
   }
+  // accumulator register r of lane l is element (k = 8*(r/4) + 4*(l/32) + r%4, o = l%32) of the tile
+  float *red = sm;  // [wave][32][32]
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int k = k0 + 2 * ti + i, o = o0 + 2 * to + j;
-      if (k < K && o < Ci) part[((i64)split * K + k) * Ci + o] = acc[i][j];
-    }
+  for (int r = 0; r < 16; ++r) {
+    const int kk = 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3);
+    red[(wave * 32 + kk) * 32 + (lane & 31)] = acc[r];
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < 32 * 32; e += 256) {
+    const int k = k0 + (e >> 5), o = o0 + (e & 31);
+    if (k < K && o < Ci)
+      part[((i64)split * K + k) * Ci + o] = (red[e] + red[1024 + e]) + (red[2048 + e] + red[3072 + e]);
+  }
 }
 
 // grad[e] = sum_split part[split][e], splits in order
@@ -307,19 +363,20 @@ __global__ __launch_bounds__(256) void attn_wgrad_reduce_kernel(const float *__r
   }
 }
 
-// The vector-shaped gradients, one workgroup each (block_sum: fixed order):
-//   blockIdx.x <  Ci : dpsi[o] = sum_cells gz * int1[o]   and   db1[o] = sum_cells gpre[o]
-//   blockIdx.x == Ci : dbpsi   = sum_cells gz,            gz = galpha * alpha * (1 - alpha)
+// The vector-shaped gradients in two stages (fixed order in both):
+//   o <  Ci : dpsi[o] = sum_cells gz * int1[o]   and   db1[o] = sum_cells gpre[o]
+//   o == Ci : dbpsi   = sum_cells gz,            gz = galpha * alpha * (1 - alpha)
+// Stage 1: workgroup (slice, o) sums its slice of the cells into part[o][slice][2].
 __global__ __launch_bounds__(256) void attn_vec_grad_kernel(const float *__restrict__ galpha,
                                                             const float *__restrict__ alpha,
                                                             const float *__restrict__ int1,
                                                             const float *__restrict__ gpre, int Ci, i64 hw,
-                                                            i64 cells, float *__restrict__ grad_psi,
-                                                            float *__restrict__ grad_b1, float *__restrict__ grad_bpsi) {
+                                                            i64 cells, i64 cells_per_slice, float *__restrict__ part) {
   __shared__ float red[2 * 4];
-  const int o = blockIdx.x;
+  const int slice = blockIdx.x, o = blockIdx.y;
+  const i64 c_begin = slice * cells_per_slice, c_end = min(cells, c_begin + cells_per_slice);
   float v[2] = {0.f, 0.f};
-  for (i64 cell = threadIdx.x; cell < cells; cell += 256) {
+  for (i64 cell = c_begin + threadIdx.x; cell < c_end; cell += 256) {
     const float al = alpha[cell];
     const float gz = galpha[cell] * al * (1.0f - al);
     if (o < Ci) {
@@ -333,12 +390,27 @@ __global__ __launch_bounds__(256) void attn_vec_grad_kernel(const float *__restr
   }
   block_sum<2>(v, red);
   if (threadIdx.x == 0) {
-    if (o < Ci) {
-      grad_psi[o] = v[0];
-      grad_b1[o] = v[1];
-    } else {
-      grad_bpsi[0] = v[0];
-    }
+    part[((i64)o * gridDim.x + slice) * 2] = v[0];
+    part[((i64)o * gridDim.x + slice) * 2 + 1] = v[1];
+  }
+}
+// Stage 2: one wavefront per o adds the slices in order.
+__global__ __launch_bounds__(64) void attn_vec_grad_finish_kernel(const float *__restrict__ part, int slices, int Ci,
+                                                                  float *__restrict__ grad_psi,
+                                                                  float *__restrict__ grad_b1,
+                                                                  float *__restrict__ grad_bpsi) {
+  const int o = blockIdx.x;
+  if (threadIdx.x != 0) return;
+  float a = 0.f, b = 0.f;
+  for (int sl = 0; sl < slices; ++sl) {
+    a += part[((i64)o * slices + sl) * 2];
+    b += part[((i64)o * slices + sl) * 2 + 1];
+  }
+  if (o < Ci) {
+    grad_psi[o] = a;
+    grad_b1[o] = b;
+  } else {
+    grad_bpsi[0] = a;
   }
 }
 
@@ -367,8 +439,13 @@ int unet_attention_f32(float *activations_int_1, float *activations_int_2, float
   const int Hg = H_x / 2, Wg = W_x / 2;
   const i64 cells = (i64)batch_size * Hg * Wg, pixels = 4 * cells;
   const GateIn in{input_x, input_g, channels_in_x, channels_in_g, Hg, Wg};
-  hipLaunchKernelGGL(attn_gate_fwd_kernel, dim3(cdiv_u(cells, CELLS)), dim3(256), 0, as_stream(s), in, weights,
-                     int_channels, activations_int_1, activations_int_2, cells);
+  const bool full = int_channels % 32 == 0 && (channels_in_x + channels_in_g) % 8 == 0;
+  if (full)
+    hipLaunchKernelGGL(attn_gate_fwd_kernel<true>, dim3(cdiv_u(cells, CELLS)), dim3(256), 0, as_stream(s), in, weights,
+                       int_channels, activations_int_1, activations_int_2, cells);
+  else
+    hipLaunchKernelGGL(attn_gate_fwd_kernel<false>, dim3(cdiv_u(cells, CELLS)), dim3(256), 0, as_stream(s), in, weights,
+                       int_channels, activations_int_1, activations_int_2, cells);
   UNET_LAUNCH_CHECK("attn_gate_fwd_kernel");
   hipLaunchKernelGGL(attn_resample_mul_kernel, dim3(ew_grid(pixels)), dim3(256), 0, as_stream(s), input_x,
                      (const float *)activations_int_2, activations, channels_in_x, H_x, W_x, pixels);
@@ -400,12 +477,16 @@ int unet_attention_backward_f32(const float *grad_activations, const float *acti
   i64 cells_per_split = (cells + splits - 1) / splits;
   cells_per_split = (cells_per_split + CELLS - 1) / CELLS * CELLS;
   splits = (cells + cells_per_split - 1) / cells_per_split;
-  // workspace: s [pixels] | weight-gradient partials [splits][K][Ci]
-  const size_t s_floats = (size_t)pixels, part_floats = (size_t)splits * K * Ci;
+  // slices of the cells for the vector-shaped gradients
+  int slices = (int)((cells + 4095) / 4096);
+  if (slices > 64) slices = 64;
+  const i64 cells_per_slice = (cells + slices - 1) / slices;
+  // workspace: s [pixels] | weight-gradient partials [splits][K][Ci] | vector partials [Ci+1][slices][2]
+  const size_t s_floats = (size_t)pixels, part_floats = (size_t)splits * K * Ci, vec_floats = (size_t)(Ci + 1) * slices * 2;
   void *ws;
-  rc = unet_workspace(&ws, sizeof(float) * (s_floats + part_floats), as_stream(s));
+  rc = unet_workspace(&ws, sizeof(float) * (s_floats + part_floats + vec_floats), as_stream(s));
   if (rc) return rc;
-  float *sbuf = (float *)ws, *part = sbuf + s_floats;
+  float *sbuf = (float *)ws, *part = sbuf + s_floats, *vec_part = part + part_floats;
   const float *psi = weights + (i64)K * Ci;
   float *grad_psi = grad_weights + (i64)K * Ci, *grad_b1 = grad_psi + Ci, *grad_bpsi = grad_b1 + Ci;
   const GateIn in{input_x, input_g, Cx, Cg, Hg, Wg};
@@ -417,9 +498,14 @@ int unet_attention_backward_f32(const float *grad_activations, const float *acti
                      activations_int_2, activations_int_1, psi, grad_activations_int_2, grad_activations_int_1, Ci,
                      H_x, W_x, cells);
   UNET_LAUNCH_CHECK("attn_cell_bwd_kernel");
-  hipLaunchKernelGGL(attn_gate_dgrad_kernel, dim3(cdiv_u(cells, CELLS)), dim3(256), 0, as_stream(s),
-                     (const float *)grad_activations_int_1, weights, Ci, Cx, Cg, Hg, Wg, grad_input_x, grad_input_g,
-                     cells);
+  if (K % 32 == 0 && Ci % 8 == 0)
+    hipLaunchKernelGGL(attn_gate_dgrad_kernel<true>, dim3(cdiv_u(cells, CELLS)), dim3(256), 0, as_stream(s),
+                       (const float *)grad_activations_int_1, weights, Ci, Cx, Cg, Hg, Wg, grad_input_x, grad_input_g,
+                       cells);
+  else
+    hipLaunchKernelGGL(attn_gate_dgrad_kernel<false>, dim3(cdiv_u(cells, CELLS)), dim3(256), 0, as_stream(s),
+                       (const float *)grad_activations_int_1, weights, Ci, Cx, Cg, Hg, Wg, grad_input_x, grad_input_g,
+                       cells);
   UNET_LAUNCH_CHECK("attn_gate_dgrad_kernel");
   hipLaunchKernelGGL(attn_wgrad_kernel, dim3(cdiv_u(K, 32), cdiv_u(Ci, 32), (unsigned)splits), dim3(256), 0,
                      as_stream(s), in, (const float *)grad_activations_int_1, Ci, part, cells, cells_per_split);
@@ -427,10 +513,13 @@ int unet_attention_backward_f32(const float *grad_activations, const float *acti
   hipLaunchKernelGGL(attn_wgrad_reduce_kernel, dim3(ew_grid((i64)K * Ci)), dim3(256), 0, as_stream(s),
                      (const float *)part, (int)splits, (i64)K * Ci, grad_weights);
   UNET_LAUNCH_CHECK("attn_wgrad_reduce_kernel");
-  hipLaunchKernelGGL(attn_vec_grad_kernel, dim3(Ci + 1), dim3(256), 0, as_stream(s),
+  hipLaunchKernelGGL(attn_vec_grad_kernel, dim3(slices, Ci + 1), dim3(256), 0, as_stream(s),
                      (const float *)grad_activations_int_2, activations_int_2, activations_int_1,
-                     (const float *)grad_activations_int_1, Ci, (i64)Hg * Wg, cells, grad_psi, grad_b1, grad_bpsi);
+                     (const float *)grad_activations_int_1, Ci, (i64)Hg * Wg, cells, cells_per_slice, vec_part);
   UNET_LAUNCH_CHECK("attn_vec_grad_kernel");
+  hipLaunchKernelGGL(attn_vec_grad_finish_kernel, dim3(Ci + 1), dim3(64), 0, as_stream(s), (const float *)vec_part,
+                     slices, Ci, grad_psi, grad_b1, grad_bpsi);
+  UNET_LAUNCH_CHECK("attn_vec_grad_finish_kernel");
   return UNET_OK;
 }
 
