@@ -105,7 +105,7 @@ def main():
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--base", type=int, default=64, help="channels of the first stage (unet4 graph)")
     ap.add_argument("--graph", default=os.environ.get("UNET_BENCH_GRAPH", "unet4_base64"),
-                    choices=["unet4_base64", "mainpy"])
+                    choices=["unet4_base64", "mainpy", "attention_unet"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="skip the per-kernel event timing")
     args = ap.parse_args()
@@ -129,8 +129,12 @@ def main():
         dist.init_process_group("nccl", device_id=device)
 
     H = W = args.size
-    graph = (torch_ref.unet_graph(H, W, 3, args.base, 4, True) if args.graph == "unet4_base64"
-             else torch_ref.main_py_graph(H, W, 3, 64))
+    if args.graph == "unet4_base64":
+        graph = torch_ref.unet_graph(H, W, 3, args.base, 4, True)
+    elif args.graph == "mainpy":
+        graph = torch_ref.main_py_graph(H, W, 3, 64)
+    else:   # the graph main.py:144-184 keeps commented out: main.py's graph with an attention gate on every skip
+        graph = torch_ref.attention_unet_graph(H, W, 3, 64)
     free0, _ = torch.cuda.mem_get_info(device)
     net = nn.NeuralNet()
     net.set_seed(1)

@@ -319,6 +319,10 @@ int unet_pack_weights_batch_bf16(const int64_t *table_device, int layers, int to
 /* NCHW fp32 -> NHWC bf16 (pixel stride ld); channels [C, Cpad) are zeroed. */
 int unet_nchw_f32_to_nhwc_bf16(const float *in, uint16_t *out, int N, int C, int H, int W, int ld, int Cpad,
                                unet_stream_t stream);
+/* out[..., c] += in[n, c, ...] for c < C (the sum is rounded to bf16): adds an fp32 NCHW gradient
+ * to an NHWC bf16 gradient buffer (cudaAddBtoA across the two layouts). */
+int unet_nchw_f32_add_to_nhwc_bf16(const float *in, uint16_t *out, int N, int C, int H, int W, int ld,
+                                   unet_stream_t stream);
 int unet_nhwc_bf16_to_nchw_f32(const uint16_t *in, float *out, int N, int C, int H, int W, int ld,
                                unet_stream_t stream);
 

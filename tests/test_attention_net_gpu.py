@@ -61,7 +61,8 @@ def test_attention_unet_train_step_matches_torch(nn):
     for i in (4, 6, 8, 12, 16, 17, 18):
         assert_close(net.layer_output(i, n), acts[i].detach().numpy(), rtol=2e-4, atol_scale=2e-5,
                      what=f"layer {i} activation")
-    assert abs(loss_val - float(ref_loss)) <= 1e-4 * abs(float(ref_loss)) + 1e-6
+    ref_loss = float(ref_loss.detach())
+    assert abs(loss_val - ref_loss) <= 1e-4 * abs(ref_loss) + 1e-6
     for layer, (off, nwb, nbn) in layout.items():
         g, r = grads[off:off + nwb + nbn], ref_grads[off:off + nwb + nbn]
         scale = np.abs(r).max()
@@ -117,3 +118,57 @@ def test_attention_layer_validation_messages(nn):
     with pytest.raises(RuntimeError, match="g that is not half the size of x"):
         nn.NeuralNet().create([conv, L(T.CONV_LAYER, [8, 8, 4, 4, 3, 1, 1], [0]), L(T.ATTENTION_LAYER, [], [0, 1])],
                               nn.DICE_LOSS)
+
+
+def test_attention_unet_on_the_bf16_path_matches_the_bf16_storage_oracle(nn):
+    """With channel counts in multiples of 32 the same graph runs on the bf16 / NHWC engine path (the gates compute
+    in fp32 between layout conversions).  Compared like the other bf16 network tests: activations against the
+    float64 oracle with bf16 storage emulated (rel <= 2e-2), gradients per layer by relative L2 error and cosine."""
+    from util import assert_close_bf16_net
+    graph = torch_ref.attention_unet_graph(32, 48, 3, 32)
+    net = make(nn, graph)
+    assert net.compute_dtype() == "bf16"
+    rng = np.random.default_rng(3)
+    n = 4
+    x = rng.standard_normal((n, 3, 32, 48)).astype(np.float32)
+    m = (rng.random((n, 32, 48)) < 0.3).astype(np.float32)
+    p0 = net.get_parameters()
+    p0 = (p0 + rng.standard_normal(p0.size).astype(np.float32) * 0.02).astype(np.float32)
+    net.set_parameters(p0)
+    loss_val = net.train_step(x, m, 1e-2, False)
+    grads = net.get_gradients()
+
+    outs = {}
+    for emu in (False, True):
+        params = torch_ref.split_params(graph, p0)
+        acts = torch_ref.forward(graph, params, torch.from_numpy(x).double(), emulate_bf16=emu)
+        ref_loss = torch_ref.dice_loss(acts[-1], torch.from_numpy(m).double())
+        ref_loss.backward()
+        outs[emu] = ([a.detach().numpy() for a in acts], float(ref_loss.detach()), torch_ref.flat_grads(graph, params))
+    acts, ref_loss, plain_grads = outs[False]
+    emu_acts, emu_loss, ref_grads = outs[True]
+    for i in range(len(graph)):
+        assert_close_bf16_net(net.layer_output(i, n), emu_acts[i], what=f"layer {i} activation vs bf16-storage oracle")
+    assert abs(loss_val - ref_loss) <= 2e-2 * abs(ref_loss) + 1e-6
+    assert abs(loss_val - emu_loss) <= 2e-3 * abs(emu_loss) + 1e-6
+    for layer, off, nwb, nbn in net.parameter_layout():
+        co = nbn // 2
+        ranges = [(off, off + nwb - co, "weights")] + ([(off + nwb, off + nwb + nbn, "gamma/beta")] if nbn else [])
+        for lo, hi, what in ranges:
+            g, r, pl = grads[lo:hi].astype(np.float64), ref_grads[lo:hi], plain_grads[lo:hi]
+            rel = np.linalg.norm(g - r) / max(np.linalg.norm(r), 1e-12)
+            cos_e = float(np.dot(g, r) / max(np.linalg.norm(g) * np.linalg.norm(r), 1e-30))
+            cos_p = float(np.dot(g, pl) / max(np.linalg.norm(g) * np.linalg.norm(pl), 1e-30))
+            assert rel <= 0.15, f"layer {layer} {what} gradient vs bf16-storage oracle: relative L2 error {rel:.3g}"
+            assert cos_e >= 0.99, f"layer {layer} {what} gradient vs bf16-storage oracle: cosine {cos_e:.4f}"
+            assert cos_p >= 0.9, f"layer {layer} {what} gradient vs float64 oracle: cosine {cos_p:.4f}"
+    # trains, and two runs give the same bits
+    losses = [net.train_step(x, m, 1e-2, True) for _ in range(8)]
+    assert losses[-1] < losses[0]
+    net2 = make(nn, graph)
+    net2.set_parameters(p0)
+    net2.train_step(x, m, 1e-2, False)
+    np.testing.assert_array_equal(net2.get_gradients(), grads)
+    # inference (running statistics, BN + ReLU folded into the conv epilogues) runs through the gates too
+    y = net.forward(x[:2], True)
+    assert y.shape[-2:] == (32, 48) and np.isfinite(y).all()

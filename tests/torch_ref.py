@@ -281,7 +281,8 @@ def forward(graph, params, x, training=True, running=None, emulate_bf16=False):
     (values only), every convolution output and every activation are rounded
     to bf16 where the module stores them in bf16, gradients are rounded where
     the module stores them in bf16, batch-norm statistics are taken from the
-    rounded convolution output, the final (narrow) layer's batch norm,
+    rounded convolution output, attention gates compute in full precision
+    on the rounded inputs and round their output, the final (narrow) layer's batch norm,
     activation and loss stay in full precision, and max pool routes gradients
     to every tied maximum.  Arithmetic stays float64."""
     rnd = _RoundBF16.apply if emulate_bf16 else (lambda t: t)
@@ -311,8 +312,8 @@ def forward(graph, params, x, training=True, running=None, emulate_bf16=False):
         elif kind == "concat":
             acts.append(torch.cat([acts[parents[0]], acts[parents[1]]], dim=1))
         elif kind == "attention":
-            acts.append(attention_gate(acts[parents[0]], acts[parents[1]], params[i]["att"],
-                                       attention_dims(graph, i)[2]))
+            acts.append(rnd(attention_gate(acts[parents[0]], acts[parents[1]], params[i]["att"],
+                                           attention_dims(graph, i)[2])))
         else:
             raise ValueError(kind)
     return acts

@@ -559,7 +559,9 @@ __global__ __launch_bounds__(256) void pack_weights_batch_kernel(const int64_t *
 }
 
 // NCHW fp32 -> NHWC bf16 with pixel stride ld; channels [C, Cpad) are zero-filled.
-// One block transposes a 32-pixel x 32-channel tile through LDS.
+// One block transposes a 32-pixel x 32-channel tile through LDS.  ACC: the converted values are added to what
+// `out` holds (channels [0, C) only).
+template <bool ACC>
 __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float *__restrict__ in, bf16_t *__restrict__ out,
                                                            int C, i64 HW, int ld, int Cpad) {
   __shared__ float t[32][33];
@@ -576,7 +578,10 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float *__restri
   for (int r = ty; r < 32; r += 8) {
     const i64 p = p0 + r;
     const int c = c0 + tx;
-    if (p < HW && c < Cpad) out[(n * HW + p) * ld + c] = (bf16_t)f32_to_bf16(t[tx][r]);
+    if (p < HW && c < Cpad) {
+      bf16_t *o = out + (n * HW + p) * ld + c;
+      *o = (bf16_t)f32_to_bf16(ACC ? t[tx][r] + bf16_to_f32(*o) : t[tx][r]);
+    }
   }
 }
 
@@ -652,7 +657,18 @@ int unet_nchw_f32_to_nhwc_bf16(const float *in, uint16_t *out, int N, int C, int
     return UNET_OK;
   }
   dim3 grid(cdiv_u(HW, 32), cdiv_u(Cpad, 32), (unsigned)N);
-  hipLaunchKernelGGL(nchw_to_nhwc_kernel, grid, dim3(256), 0, as_stream(s), in, out, C, HW, ld, Cpad);
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel<false>, grid, dim3(256), 0, as_stream(s), in, out, C, HW, ld, Cpad);
+  UNET_LAUNCH_CHECK("nchw_to_nhwc_kernel");
+  return UNET_OK;
+}
+
+int unet_nchw_f32_add_to_nhwc_bf16(const float *in, uint16_t *out, int N, int C, int H, int W, int ld,
+                                   unet_stream_t s) {
+  UNET_REQUIRE(in && out, "unet_nchw_f32_add_to_nhwc_bf16: NULL pointer");
+  UNET_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0 && ld >= C && N <= 65535, "unet_nchw_f32_add_to_nhwc_bf16: bad sizes");
+  const i64 HW = (i64)H * W;
+  dim3 grid(cdiv_u(HW, 32), cdiv_u(C, 32), (unsigned)N);
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel<true>, grid, dim3(256), 0, as_stream(s), in, out, C, HW, ld, C);
   UNET_LAUNCH_CHECK("nchw_to_nhwc_kernel");
   return UNET_OK;
 }
