@@ -217,6 +217,23 @@ int unet_attention_backward_f32(const float *grad_activations, const float *acti
                                 int batch_size, int H_x, int W_x, int channels_in_x,
                                 int channels_in_g, int int_channels, unet_stream_t stream);
 
+/* The same gate between NHWC bf16 tensors (pixel strides x_ld, g_ld, out_ld in elements; a tensor may be
+ * a channel slice of a wider buffer): the projections, psi and their gradients run in fp32 on x gathered
+ * at the even pixels, the passes over the full-resolution tensors read and write bf16 directly.
+ * int_1 / int_2 are fp32 as above and must be kept for the backward.  The incoming gradient is dy (+ dy2
+ * when not NULL); dx and dg are written, or added to when the accumulate flag is set. */
+int unet_attention_bf16(const uint16_t *x, int x_ld, const uint16_t *g, int g_ld, const float *weights,
+                        float *activations_int_1, float *activations_int_2, uint16_t *out, int out_ld,
+                        int batch_size, int H_x, int W_x, int channels_in_x, int channels_in_g,
+                        int int_channels, unet_stream_t stream);
+int unet_attention_backward_bf16(const uint16_t *dy, int dy_ld, const uint16_t *dy2, int dy2_ld,
+                                 const uint16_t *x, int x_ld, const uint16_t *g, int g_ld,
+                                 const float *weights, const float *activations_int_1,
+                                 const float *activations_int_2, uint16_t *dx, int dx_ld, int dx_accumulate,
+                                 uint16_t *dg, int dg_ld, int dg_accumulate, float *grad_weights,
+                                 int batch_size, int H_x, int W_x, int channels_in_x, int channels_in_g,
+                                 int int_channels, unet_stream_t stream);
+
 /* ---- upsample = transposed conv, kernel = stride = scale ---------------- */
 /* (cuda_lib.h:79-88, 213-224) */
 

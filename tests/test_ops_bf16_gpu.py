@@ -467,6 +467,7 @@ HEAD_CASES = [
     (1, 64, 21, 37),     # ragged tiles
     (2, 32, 16, 16),
     (1, 100, 18, 16),    # C_in padded 100 -> 128
+    (2, 128, 40, 24),    # two 64-channel chunks of the halo, several tiles per workgroup
 ]
 
 

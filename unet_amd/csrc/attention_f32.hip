@@ -15,6 +15,7 @@
 // Unlike the reference's backward (fp32 atomicAdd everywhere) every sum here has a fixed order:
 // gathers instead of scatters, one workgroup per output tile for the weight gradient, split
 // partials added in index order.
+#include "bf16_util.h"
 #include "common.h"
 
 namespace {
@@ -40,16 +41,14 @@ __device__ __forceinline__ float blend_value(const float *__restrict__ alpha_n, 
   return r2 * bh.f + r1 * (1.0f - bh.f);
 }
 
-// Input channel k of cell (n, h, w): x at the even pixels for k < Cx, g otherwise.
+// Input channel k of cell (n, h, w): x at the even pixels for k < Cx, g otherwise.  x_dense: x was
+// gathered beforehand and is [N,Cx,Hg,Wg] like g.
 struct GateIn {
   const float *x, *g;
   int Cx, Cg, Hg, Wg;
+  int x_dense;
 };
-__device__ __forceinline__ float gate_input(const GateIn &in, int k, i64 n, int h, int w) {
-  if (k < in.Cx) return in.x[((n * in.Cx + k) * (2 * in.Hg) + 2 * h) * (i64)(2 * in.Wg) + 2 * w];
-  return in.g[((n * in.Cg + (k - in.Cx)) * in.Hg + h) * (i64)in.Wg + w];
-}
-// The same through two per-cell base pointers: channel k is one plane stride further.
+// Two per-cell base pointers: channel k is one plane stride further.
 struct GateCell {
   const float *xp, *gp;
   i64 xplane, gplane;
@@ -58,8 +57,8 @@ struct GateCell {
 __device__ __forceinline__ GateCell gate_cell(const GateIn &in, i64 n, int h, int w) {
   GateCell c;
   c.gplane = (i64)in.Hg * in.Wg;
-  c.xplane = 4 * c.gplane;
-  c.xp = in.x + n * in.Cx * c.xplane + (i64)(2 * h) * (2 * in.Wg) + 2 * w;
+  c.xplane = in.x_dense ? c.gplane : 4 * c.gplane;
+  c.xp = in.x + n * in.Cx * c.xplane + (in.x_dense ? (i64)h * in.Wg + w : (i64)(2 * h) * (2 * in.Wg) + 2 * w);
   c.gp = in.g + n * in.Cg * c.gplane + (i64)h * in.Wg + w;
   c.Cx = in.Cx;
   return c;
@@ -239,13 +238,14 @@ __global__ __launch_bounds__(256) void attn_cell_bwd_kernel(const float *__restr
 
 // Input gradients of the two 1x1 projections: dst[k] (+)= sum_o gpre[o] * W[k][o] per cell.
 // Same thread layout as the forward: 64 cells x 4 groups of input channels, eight at a time.
-// The x part lands on the even pixels of grad_x, which already holds the resample term.
+// The x part lands on the even pixels of grad_x, which already holds the resample term (or, x_dense, is written
+// alone at the resolution of g).
 // FULL: every group has a multiple of eight input channels and Ci is a multiple of eight.
 template <bool FULL>
 __global__ __launch_bounds__(256) void attn_gate_dgrad_kernel(const float *__restrict__ gpre,
                                                               const float *__restrict__ params, int Ci, int Cx,
                                                               int Cg, int Hg, int Wg, float *__restrict__ grad_x,
-                                                              float *__restrict__ grad_g, i64 cells) {
+                                                              float *__restrict__ grad_g, i64 cells, int x_dense) {
   const int K = Cx + Cg;
   const int lane = threadIdx.x & 63, grp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const i64 cell = (i64)blockIdx.x * CELLS + lane;
@@ -277,8 +277,12 @@ __global__ __launch_bounds__(256) void attn_gate_dgrad_kernel(const float *__res
       const int k = k0 + j;
       if (!FULL && k >= k_end) break;
       if (k < Cx) {
-        const i64 idx = ((n * Cx + k) * (2 * Hg) + 2 * h) * (i64)(2 * Wg) + 2 * w;
-        grad_x[idx] += acc[j];
+        if (x_dense) {  // the projection's term alone, [N,Cx,Hg,Wg]
+          grad_x[((n * Cx + k) * Hg + h) * (i64)Wg + w] = acc[j];
+        } else {
+          const i64 idx = ((n * Cx + k) * (2 * Hg) + 2 * h) * (i64)(2 * Wg) + 2 * w;
+          grad_x[idx] += acc[j];
+        }
       } else {
         grad_g[((n * Cg + (k - Cx)) * Hg + h) * (i64)Wg + w] = acc[j];
       }
@@ -414,6 +418,144 @@ __global__ __launch_bounds__(64) void attn_vec_grad_finish_kernel(const float *_
   }
 }
 
+// ---- the gate between NHWC bf16 tensors ---------------------------------------------------------
+// The projections, psi and their gradients stay on the fp32 kernels above (on x gathered at the even pixels);
+// the passes over the full-resolution tensors read and write NHWC bf16 directly.
+
+// xs[n,c,h,w] (fp32, resolution of g) = x[n,2h,2w,c] (NHWC bf16, pixel stride ld): a 32-cell x 32-channel
+// tile transposed through LDS.
+__global__ __launch_bounds__(256) void attn_gather_x_kernel(const bf16_t *__restrict__ x, int ld,
+                                                            float *__restrict__ xs, int Cx, int Hg, int Wg) {
+  __shared__ float t[32][33];
+  const i64 n = blockIdx.z, HWg = (i64)Hg * Wg;
+  const i64 p0 = (i64)blockIdx.x * 32;
+  const int c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int r = ty; r < 32; r += 8) {
+    const i64 p = p0 + r;
+    const int c = c0 + tx;
+    float v = 0.f;
+    if (p < HWg && c < Cx) {
+      const int h = (int)(p / Wg), w = (int)(p - (i64)h * Wg);
+      v = bf16_to_f32(x[((n * 2 * Hg + 2 * h) * (i64)(2 * Wg) + 2 * w) * ld + c]);
+    }
+    t[r][tx] = v;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int c = c0 + r;
+    const i64 p = p0 + tx;
+    if (c < Cx && p < HWg) xs[(n * Cx + c) * HWg + p] = t[tx][r];
+  }
+}
+
+__device__ __forceinline__ void unpack8f(const uint4 &r, float (&v)[8]) {
+  const uint32_t w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    v[2 * j] = bf16_to_f32(w[j] & 0xffffu);
+    v[2 * j + 1] = bf16_to_f32(w[j] >> 16);
+  }
+}
+__device__ __forceinline__ uint4 pack8f(const float (&v)[8]) {
+  uint32_t w[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) w[j] = f32_to_bf16(v[2 * j]) | (f32_to_bf16(v[2 * j + 1]) << 16);
+  return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+// out = bf16(x * blend(alpha)), one lane per (pixel, 8 channels)
+__global__ __launch_bounds__(256) void attn_apply_bf16_kernel(const bf16_t *__restrict__ x, int x_ld,
+                                                              const float *__restrict__ alpha,
+                                                              bf16_t *__restrict__ out, int out_ld, int CG, int Hx,
+                                                              int Wx, i64 total) {
+  const int Hg = Hx / 2, Wg = Wx / 2;
+  const i64 hw = (i64)Hx * Wx;
+  for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (i64)gridDim.x * blockDim.x) {
+    const int cg = (int)(i % CG);
+    const i64 p = i / CG, n = p / hw;
+    const int rem = (int)(p - n * hw);
+    const int h = rem / Wx, w = rem - h * Wx;
+    const float a = blend_value(alpha + n * (i64)Hg * Wg, h, w, Hg, Wg);
+    float v[8];
+    unpack8f(*reinterpret_cast<const uint4 *>(x + p * x_ld + cg * 8), v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] *= a;
+    *reinterpret_cast<uint4 *>(out + p * out_ld + cg * 8) = pack8f(v);
+  }
+}
+
+// s[pixel] = sum_c (dy1 + dy2) * x: eight lanes per pixel, each walking every eighth 8-channel group; the
+// eight partial sums are added by a fixed xor butterfly.
+__global__ __launch_bounds__(256) void attn_sums_bf16_kernel(const bf16_t *__restrict__ dy1, int ld1,
+                                                             const bf16_t *__restrict__ dy2, int ld2,
+                                                             const bf16_t *__restrict__ x, int x_ld,
+                                                             float *__restrict__ s, int CG, i64 pixels) {
+  const int sub = threadIdx.x & 7;
+  // the eight lanes of a group share p, so they leave the loop together
+  for (i64 p = ((i64)blockIdx.x * blockDim.x + threadIdx.x) >> 3; p < pixels; p += ((i64)gridDim.x * blockDim.x) >> 3) {
+    float acc = 0.f;
+    for (int cg = sub; cg < CG; cg += 8) {
+      float g[8], xv[8];
+      unpack8f(*reinterpret_cast<const uint4 *>(dy1 + p * ld1 + cg * 8), g);
+      if (dy2) {
+        float g2[8];
+        unpack8f(*reinterpret_cast<const uint4 *>(dy2 + p * ld2 + cg * 8), g2);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) g[j] += g2[j];
+      }
+      unpack8f(*reinterpret_cast<const uint4 *>(x + p * x_ld + cg * 8), xv);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc = fmaf(g[j], xv[j], acc);
+    }
+    acc += __shfl_xor(acc, 1, 64);
+    acc += __shfl_xor(acc, 2, 64);
+    acc += __shfl_xor(acc, 4, 64);
+    if (sub == 0) s[p] = acc;
+  }
+}
+
+// dx (+)= bf16((dy1 + dy2) * blend(alpha) + [even pixel] grad_xs[n,c,h/2,w/2]), one lane per (pixel, 8 channels)
+__global__ __launch_bounds__(256) void attn_apply_bwd_bf16_kernel(const bf16_t *__restrict__ dy1, int ld1,
+                                                                  const bf16_t *__restrict__ dy2, int ld2,
+                                                                  const float *__restrict__ alpha,
+                                                                  const float *__restrict__ grad_xs,
+                                                                  bf16_t *__restrict__ dx, int dx_ld, int accumulate,
+                                                                  int CG, int Hx, int Wx, i64 total) {
+  const int Hg = Hx / 2, Wg = Wx / 2, Cx = CG * 8;
+  const i64 hw = (i64)Hx * Wx, hwg = (i64)Hg * Wg;
+  for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (i64)gridDim.x * blockDim.x) {
+    const int cg = (int)(i % CG);
+    const i64 p = i / CG, n = p / hw;
+    const int rem = (int)(p - n * hw);
+    const int h = rem / Wx, w = rem - h * Wx;
+    const float a = blend_value(alpha + n * hwg, h, w, Hg, Wg);
+    float g[8];
+    unpack8f(*reinterpret_cast<const uint4 *>(dy1 + p * ld1 + cg * 8), g);
+    if (dy2) {
+      float g2[8];
+      unpack8f(*reinterpret_cast<const uint4 *>(dy2 + p * ld2 + cg * 8), g2);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) g[j] += g2[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) g[j] *= a;
+    if (((h | w) & 1) == 0) {
+      const float *gx = grad_xs + (n * Cx + cg * 8) * hwg + (i64)(h >> 1) * Wg + (w >> 1);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) g[j] += gx[j * hwg];
+    }
+    bf16_t *dst = dx + p * dx_ld + cg * 8;
+    if (accumulate) {
+      float o[8];
+      unpack8f(*reinterpret_cast<const uint4 *>(dst), o);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) g[j] += o[j];
+    }
+    *reinterpret_cast<uint4 *>(dst) = pack8f(g);
+  }
+}
+
 int check_attention_shape(const char *who, int batch, int H_x, int W_x, int Cx, int Cg, int Ci) {
   UNET_REQUIRE(batch > 0 && H_x >= 2 && W_x >= 2 && H_x % 2 == 0 && W_x % 2 == 0 && Cx > 0 && Cg > 0 && Ci > 0,
                "%s: need batch, channel counts > 0 and even H_x, W_x >= 2 (g is half the size of x)", who);
@@ -438,7 +580,7 @@ int unet_attention_f32(float *activations_int_1, float *activations_int_2, float
   if (rc) return rc;
   const int Hg = H_x / 2, Wg = W_x / 2;
   const i64 cells = (i64)batch_size * Hg * Wg, pixels = 4 * cells;
-  const GateIn in{input_x, input_g, channels_in_x, channels_in_g, Hg, Wg};
+  const GateIn in{input_x, input_g, channels_in_x, channels_in_g, Hg, Wg, 0};
   const bool full = int_channels % 32 == 0 && (channels_in_x + channels_in_g) % 8 == 0;
   if (full)
     hipLaunchKernelGGL(attn_gate_fwd_kernel<true>, dim3(cdiv_u(cells, CELLS)), dim3(256), 0, as_stream(s), in, weights,
@@ -453,6 +595,68 @@ int unet_attention_f32(float *activations_int_1, float *activations_int_2, float
   return UNET_OK;
 }
 
+// Everything of the backward after s = sum_c grad_out * x is known: cell gathers, sigmoid / ReLU backward,
+// input and weight gradients of the projections.  grad_x is the full-resolution tensor (the projection's
+// term is added at its even pixels) or, in.x_dense, the [N,Cx,Hg,Wg] term alone.
+struct AttnPlan {
+  i64 cells, splits, cells_per_split, cells_per_slice;
+  int slices;
+  size_t part_floats, vec_floats;
+};
+static AttnPlan attention_plan(int batch, int Hg, int Wg, int K, int Ci) {
+  AttnPlan p;
+  p.cells = (i64)batch * Hg * Wg;
+  // weight-gradient split over the cells: enough workgroups to fill the device when the tile count is small
+  const int tiles = (int)cdiv_u(K, 32) * (int)cdiv_u(Ci, 32);
+  i64 splits = (512 + tiles - 1) / tiles;
+  const i64 max_splits = (p.cells + 4 * CELLS - 1) / (4 * CELLS);
+  if (splits > max_splits) splits = max_splits;
+  if (splits > 1024) splits = 1024;
+  if (splits < 1) splits = 1;
+  p.cells_per_split = (p.cells + splits - 1) / splits;
+  p.cells_per_split = (p.cells_per_split + CELLS - 1) / CELLS * CELLS;
+  p.splits = (p.cells + p.cells_per_split - 1) / p.cells_per_split;
+  // slices of the cells for the vector-shaped gradients
+  p.slices = (int)((p.cells + 4095) / 4096);
+  if (p.slices > 64) p.slices = 64;
+  p.cells_per_slice = (p.cells + p.slices - 1) / p.slices;
+  p.part_floats = (size_t)p.splits * K * Ci;
+  p.vec_floats = (size_t)(Ci + 1) * p.slices * 2;
+  return p;
+}
+static int attention_backward_core(const AttnPlan &pl, const float *sbuf, const float *int1, const float *alpha,
+                                   const GateIn &in, const float *weights, float *gpre, float *galpha, float *grad_x,
+                                   float *grad_g, float *grad_weights, float *part, float *vec_part, int Ci, int H_x,
+                                   int W_x, hipStream_t st) {
+  const int Cx = in.Cx, Cg = in.Cg, K = Cx + Cg, Hg = in.Hg, Wg = in.Wg;
+  const i64 cells = pl.cells;
+  const float *psi = weights + (i64)K * Ci;
+  float *grad_psi = grad_weights + (i64)K * Ci, *grad_b1 = grad_psi + Ci, *grad_bpsi = grad_b1 + Ci;
+  hipLaunchKernelGGL(attn_cell_bwd_kernel, dim3(ew_grid(cells)), dim3(256), 0, st, sbuf, alpha, int1, psi, galpha,
+                     gpre, Ci, H_x, W_x, cells);
+  UNET_LAUNCH_CHECK("attn_cell_bwd_kernel");
+  if (K % 32 == 0 && Ci % 8 == 0)
+    hipLaunchKernelGGL(attn_gate_dgrad_kernel<true>, dim3(cdiv_u(cells, CELLS)), dim3(256), 0, st, (const float *)gpre,
+                       weights, Ci, Cx, Cg, Hg, Wg, grad_x, grad_g, cells, in.x_dense);
+  else
+    hipLaunchKernelGGL(attn_gate_dgrad_kernel<false>, dim3(cdiv_u(cells, CELLS)), dim3(256), 0, st,
+                       (const float *)gpre, weights, Ci, Cx, Cg, Hg, Wg, grad_x, grad_g, cells, in.x_dense);
+  UNET_LAUNCH_CHECK("attn_gate_dgrad_kernel");
+  hipLaunchKernelGGL(attn_wgrad_kernel, dim3(cdiv_u(K, 32), cdiv_u(Ci, 32), (unsigned)pl.splits), dim3(256), 0, st, in,
+                     (const float *)gpre, Ci, part, cells, pl.cells_per_split);
+  UNET_LAUNCH_CHECK("attn_wgrad_kernel");
+  hipLaunchKernelGGL(attn_wgrad_reduce_kernel, dim3(ew_grid((i64)K * Ci)), dim3(256), 0, st, (const float *)part,
+                     (int)pl.splits, (i64)K * Ci, grad_weights);
+  UNET_LAUNCH_CHECK("attn_wgrad_reduce_kernel");
+  hipLaunchKernelGGL(attn_vec_grad_kernel, dim3(pl.slices, Ci + 1), dim3(256), 0, st, (const float *)galpha, alpha,
+                     int1, (const float *)gpre, Ci, (i64)Hg * Wg, cells, pl.cells_per_slice, vec_part);
+  UNET_LAUNCH_CHECK("attn_vec_grad_kernel");
+  hipLaunchKernelGGL(attn_vec_grad_finish_kernel, dim3(Ci + 1), dim3(64), 0, st, (const float *)vec_part, pl.slices,
+                     Ci, grad_psi, grad_b1, grad_bpsi);
+  UNET_LAUNCH_CHECK("attn_vec_grad_finish_kernel");
+  return UNET_OK;
+}
+
 int unet_attention_backward_f32(const float *grad_activations, const float *activations_int_1,
                                 const float *activations_int_2, const float *input_x, const float *input_g,
                                 const float *weights, float *grad_activations_int_1, float *grad_activations_int_2,
@@ -464,63 +668,115 @@ int unet_attention_backward_f32(const float *grad_activations, const float *acti
   int rc = check_attention_shape("unet_attention_backward_f32", batch_size, H_x, W_x, channels_in_x, channels_in_g,
                                  int_channels);
   if (rc) return rc;
-  const int Cx = channels_in_x, Cg = channels_in_g, Ci = int_channels, K = Cx + Cg;
+  const int Cx = channels_in_x, Cg = channels_in_g, Ci = int_channels;
   const int Hg = H_x / 2, Wg = W_x / 2;
-  const i64 cells = (i64)batch_size * Hg * Wg, pixels = 4 * cells;
-  // weight-gradient split over the cells: enough workgroups to fill the device when the tile count is small
-  const int tiles = (int)cdiv_u(K, 32) * (int)cdiv_u(Ci, 32);
-  i64 splits = (512 + tiles - 1) / tiles;
-  const i64 max_splits = (cells + 4 * CELLS - 1) / (4 * CELLS);
-  if (splits > max_splits) splits = max_splits;
-  if (splits > 1024) splits = 1024;
-  if (splits < 1) splits = 1;
-  i64 cells_per_split = (cells + splits - 1) / splits;
-  cells_per_split = (cells_per_split + CELLS - 1) / CELLS * CELLS;
-  splits = (cells + cells_per_split - 1) / cells_per_split;
-  // slices of the cells for the vector-shaped gradients
-  int slices = (int)((cells + 4095) / 4096);
-  if (slices > 64) slices = 64;
-  const i64 cells_per_slice = (cells + slices - 1) / slices;
+  const AttnPlan pl = attention_plan(batch_size, Hg, Wg, Cx + Cg, Ci);
+  const i64 pixels = 4 * pl.cells;
   // workspace: s [pixels] | weight-gradient partials [splits][K][Ci] | vector partials [Ci+1][slices][2]
-  const size_t s_floats = (size_t)pixels, part_floats = (size_t)splits * K * Ci, vec_floats = (size_t)(Ci + 1) * slices * 2;
   void *ws;
-  rc = unet_workspace(&ws, sizeof(float) * (s_floats + part_floats + vec_floats), as_stream(s));
+  rc = unet_workspace(&ws, sizeof(float) * ((size_t)pixels + pl.part_floats + pl.vec_floats), as_stream(s));
   if (rc) return rc;
-  float *sbuf = (float *)ws, *part = sbuf + s_floats, *vec_part = part + part_floats;
-  const float *psi = weights + (i64)K * Ci;
-  float *grad_psi = grad_weights + (i64)K * Ci, *grad_b1 = grad_psi + Ci, *grad_bpsi = grad_b1 + Ci;
-  const GateIn in{input_x, input_g, Cx, Cg, Hg, Wg};
-
+  float *sbuf = (float *)ws, *part = sbuf + pixels, *vec_part = part + pl.part_floats;
+  const GateIn in{input_x, input_g, Cx, Cg, Hg, Wg, 0};
   hipLaunchKernelGGL(attn_resample_bwd_kernel, dim3(ew_grid(pixels)), dim3(256), 0, as_stream(s), grad_activations,
                      input_x, activations_int_2, grad_input_x, sbuf, Cx, H_x, W_x, pixels);
   UNET_LAUNCH_CHECK("attn_resample_bwd_kernel");
-  hipLaunchKernelGGL(attn_cell_bwd_kernel, dim3(ew_grid(cells)), dim3(256), 0, as_stream(s), (const float *)sbuf,
-                     activations_int_2, activations_int_1, psi, grad_activations_int_2, grad_activations_int_1, Ci,
-                     H_x, W_x, cells);
-  UNET_LAUNCH_CHECK("attn_cell_bwd_kernel");
-  if (K % 32 == 0 && Ci % 8 == 0)
-    hipLaunchKernelGGL(attn_gate_dgrad_kernel<true>, dim3(cdiv_u(cells, CELLS)), dim3(256), 0, as_stream(s),
-                       (const float *)grad_activations_int_1, weights, Ci, Cx, Cg, Hg, Wg, grad_input_x, grad_input_g,
-                       cells);
-  else
-    hipLaunchKernelGGL(attn_gate_dgrad_kernel<false>, dim3(cdiv_u(cells, CELLS)), dim3(256), 0, as_stream(s),
-                       (const float *)grad_activations_int_1, weights, Ci, Cx, Cg, Hg, Wg, grad_input_x, grad_input_g,
-                       cells);
-  UNET_LAUNCH_CHECK("attn_gate_dgrad_kernel");
-  hipLaunchKernelGGL(attn_wgrad_kernel, dim3(cdiv_u(K, 32), cdiv_u(Ci, 32), (unsigned)splits), dim3(256), 0,
-                     as_stream(s), in, (const float *)grad_activations_int_1, Ci, part, cells, cells_per_split);
-  UNET_LAUNCH_CHECK("attn_wgrad_kernel");
-  hipLaunchKernelGGL(attn_wgrad_reduce_kernel, dim3(ew_grid((i64)K * Ci)), dim3(256), 0, as_stream(s),
-                     (const float *)part, (int)splits, (i64)K * Ci, grad_weights);
-  UNET_LAUNCH_CHECK("attn_wgrad_reduce_kernel");
-  hipLaunchKernelGGL(attn_vec_grad_kernel, dim3(slices, Ci + 1), dim3(256), 0, as_stream(s),
-                     (const float *)grad_activations_int_2, activations_int_2, activations_int_1,
-                     (const float *)grad_activations_int_1, Ci, (i64)Hg * Wg, cells, cells_per_slice, vec_part);
-  UNET_LAUNCH_CHECK("attn_vec_grad_kernel");
-  hipLaunchKernelGGL(attn_vec_grad_finish_kernel, dim3(Ci + 1), dim3(64), 0, as_stream(s), (const float *)vec_part,
-                     slices, Ci, grad_psi, grad_b1, grad_bpsi);
-  UNET_LAUNCH_CHECK("attn_vec_grad_finish_kernel");
+  return attention_backward_core(pl, sbuf, activations_int_1, activations_int_2, in, weights, grad_activations_int_1,
+                                 grad_activations_int_2, grad_input_x, grad_input_g, grad_weights, part, vec_part, Ci,
+                                 H_x, W_x, as_stream(s));
+}
+
+static int check_attention_views(const char *who, const void *x, int x_ld, const void *g, int g_ld, int Cx, int Cg) {
+  UNET_REQUIRE(x && g && Cx % 8 == 0 && Cg % 8 == 0 && x_ld >= Cx && g_ld >= Cg && x_ld % 8 == 0 && g_ld % 8 == 0 &&
+                   (((uintptr_t)x | (uintptr_t)g) & 15) == 0,
+               "%s: x and g must be 16-byte aligned NHWC bf16 views with channel counts and pixel strides in "
+               "multiples of 8", who);
   return UNET_OK;
+}
+
+int unet_attention_bf16(const uint16_t *x, int x_ld, const uint16_t *g, int g_ld, const float *weights,
+                        float *activations_int_1, float *activations_int_2, uint16_t *out, int out_ld, int batch_size,
+                        int H_x, int W_x, int channels_in_x, int channels_in_g, int int_channels, unet_stream_t s) {
+  UNET_REQUIRE(weights && activations_int_1 && activations_int_2 && out, "unet_attention_bf16: NULL pointer");
+  int rc = check_attention_shape("unet_attention_bf16", batch_size, H_x, W_x, channels_in_x, channels_in_g, int_channels);
+  if (!rc) rc = check_attention_views("unet_attention_bf16", x, x_ld, g, g_ld, channels_in_x, channels_in_g);
+  if (rc) return rc;
+  UNET_REQUIRE(out_ld >= channels_in_x && out_ld % 8 == 0 && ((uintptr_t)out & 15) == 0 && batch_size <= 65535,
+               "unet_attention_bf16: out must be a 16-byte aligned view with a pixel stride multiple of 8");
+  const int Cx = channels_in_x, Cg = channels_in_g, Ci = int_channels, Hg = H_x / 2, Wg = W_x / 2;
+  const i64 cells = (i64)batch_size * Hg * Wg, pixels = 4 * cells;
+  // workspace: xs [cells][Cx] | g in fp32 [cells][Cg]
+  void *ws;
+  rc = unet_workspace(&ws, sizeof(float) * (size_t)cells * (Cx + Cg), as_stream(s));
+  if (rc) return rc;
+  float *xs = (float *)ws, *gf = xs + (size_t)cells * Cx;
+  hipLaunchKernelGGL(attn_gather_x_kernel, dim3(cdiv_u((i64)Hg * Wg, 32), cdiv_u(Cx, 32), (unsigned)batch_size), dim3(256), 0,
+                     as_stream(s), x, x_ld, xs, Cx, Hg, Wg);
+  UNET_LAUNCH_CHECK("attn_gather_x_kernel");
+  rc = unet_nhwc_bf16_to_nchw_f32(g, gf, batch_size, Cg, Hg, Wg, g_ld, s);
+  if (rc) return rc;
+  const GateIn in{xs, gf, Cx, Cg, Hg, Wg, 1};
+  if (Ci % 32 == 0 && (Cx + Cg) % 8 == 0)
+    hipLaunchKernelGGL(attn_gate_fwd_kernel<true>, dim3(cdiv_u(cells, CELLS)), dim3(256), 0, as_stream(s), in, weights,
+                       Ci, activations_int_1, activations_int_2, cells);
+  else
+    hipLaunchKernelGGL(attn_gate_fwd_kernel<false>, dim3(cdiv_u(cells, CELLS)), dim3(256), 0, as_stream(s), in, weights,
+                       Ci, activations_int_1, activations_int_2, cells);
+  UNET_LAUNCH_CHECK("attn_gate_fwd_kernel");
+  const i64 total = pixels * (Cx / 8);
+  hipLaunchKernelGGL(attn_apply_bf16_kernel, dim3(ew_grid(total)), dim3(256), 0, as_stream(s), x, x_ld,
+                     (const float *)activations_int_2, out, out_ld, Cx / 8, H_x, W_x, total);
+  UNET_LAUNCH_CHECK("attn_apply_bf16_kernel");
+  return UNET_OK;
+}
+
+int unet_attention_backward_bf16(const uint16_t *dy, int dy_ld, const uint16_t *dy2, int dy2_ld, const uint16_t *x,
+                                 int x_ld, const uint16_t *g, int g_ld, const float *weights,
+                                 const float *activations_int_1, const float *activations_int_2, uint16_t *dx,
+                                 int dx_ld, int dx_accumulate, uint16_t *dg, int dg_ld, int dg_accumulate,
+                                 float *grad_weights, int batch_size, int H_x, int W_x, int channels_in_x,
+                                 int channels_in_g, int int_channels, unet_stream_t s) {
+  UNET_REQUIRE(dy && weights && activations_int_1 && activations_int_2 && dx && dg && grad_weights,
+               "unet_attention_backward_bf16: NULL pointer");
+  int rc = check_attention_shape("unet_attention_backward_bf16", batch_size, H_x, W_x, channels_in_x, channels_in_g,
+                                 int_channels);
+  if (!rc) rc = check_attention_views("unet_attention_backward_bf16", x, x_ld, g, g_ld, channels_in_x, channels_in_g);
+  if (!rc) rc = check_attention_views("unet_attention_backward_bf16 (gradients)", dx, dx_ld, dg, dg_ld, channels_in_x, channels_in_g);
+  if (rc) return rc;
+  UNET_REQUIRE(dy_ld >= channels_in_x && dy_ld % 8 == 0 && ((uintptr_t)dy & 15) == 0 &&
+                   (!dy2 || (dy2_ld >= channels_in_x && dy2_ld % 8 == 0 && ((uintptr_t)dy2 & 15) == 0)) &&
+                   batch_size <= 65535,
+               "unet_attention_backward_bf16: dy (and dy2) must be 16-byte aligned views with pixel strides in multiples of 8");
+  const int Cx = channels_in_x, Cg = channels_in_g, Ci = int_channels, Hg = H_x / 2, Wg = W_x / 2;
+  const AttnPlan pl = attention_plan(batch_size, Hg, Wg, Cx + Cg, Ci);
+  const i64 cells = pl.cells, pixels = 4 * cells;
+  // workspace: xs | g fp32 | s | galpha | gpre | grad_xs | grad_g fp32 | weight-gradient partials | vector partials
+  const size_t n_xs = (size_t)cells * Cx, n_g = (size_t)cells * Cg, n_pre = (size_t)cells * Ci;
+  void *ws;
+  rc = unet_workspace(&ws, sizeof(float) * (2 * n_xs + 2 * n_g + (size_t)pixels + (size_t)cells + n_pre +
+                                            pl.part_floats + pl.vec_floats), as_stream(s));
+  if (rc) return rc;
+  float *xs = (float *)ws, *gf = xs + n_xs, *sbuf = gf + n_g, *galpha = sbuf + pixels, *gpre = galpha + cells;
+  float *grad_xs = gpre + n_pre, *grad_gf = grad_xs + n_xs, *part = grad_gf + n_g, *vec_part = part + pl.part_floats;
+  hipLaunchKernelGGL(attn_gather_x_kernel, dim3(cdiv_u((i64)Hg * Wg, 32), cdiv_u(Cx, 32), (unsigned)batch_size), dim3(256), 0,
+                     as_stream(s), x, x_ld, xs, Cx, Hg, Wg);
+  UNET_LAUNCH_CHECK("attn_gather_x_kernel");
+  rc = unet_nhwc_bf16_to_nchw_f32(g, gf, batch_size, Cg, Hg, Wg, g_ld, s);
+  if (rc) return rc;
+  hipLaunchKernelGGL(attn_sums_bf16_kernel, dim3(ew_grid(pixels * 8)), dim3(256), 0, as_stream(s), dy, dy_ld, dy2,
+                     dy2_ld, x, x_ld, sbuf, Cx / 8, pixels);
+  UNET_LAUNCH_CHECK("attn_sums_bf16_kernel");
+  const GateIn in{xs, gf, Cx, Cg, Hg, Wg, 1};
+  rc = attention_backward_core(pl, sbuf, activations_int_1, activations_int_2, in, weights, gpre, galpha, grad_xs,
+                               grad_gf, grad_weights, part, vec_part, Ci, H_x, W_x, as_stream(s));
+  if (rc) return rc;
+  const i64 total = pixels * (Cx / 8);
+  hipLaunchKernelGGL(attn_apply_bwd_bf16_kernel, dim3(ew_grid(total)), dim3(256), 0, as_stream(s), dy, dy_ld, dy2,
+                     dy2_ld, activations_int_2, (const float *)grad_xs, dx, dx_ld, dx_accumulate, Cx / 8, H_x, W_x,
+                     total);
+  UNET_LAUNCH_CHECK("attn_apply_bwd_bf16_kernel");
+  if (dg_accumulate) return unet_nchw_f32_add_to_nhwc_bf16(grad_gf, dg, batch_size, Cg, Hg, Wg, dg_ld, s);
+  return unet_nchw_f32_to_nhwc_bf16(grad_gf, dg, batch_size, Cg, Hg, Wg, dg_ld, Cg, s);
 }
 
 }  // extern "C"

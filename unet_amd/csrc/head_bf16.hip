@@ -25,35 +25,43 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const bf16_t *__restrict_
                                                        const uint32_t *__restrict__ wt,  // [CI/32][tap][CoP][32] bf16, rows co = 0 used
                                                        int w_tap_stride_dw, const float *__restrict__ bias,
                                                        float *__restrict__ out, int H, int W, int tilesX) {
-  constexpr int PPR = CI / 8, PITCH = CI * 2 + 16, PIECES = NPIX * PPR;
+  // The halo is staged at most 64 channels at a time: a 128-channel halo (88 KB) would leave one workgroup
+  // per CU and nothing to cover its load phase.
+  constexpr int CK = CI > 64 ? 64 : CI;
+  constexpr int PPR = CK / 8, PITCH = CK * 2 + 16, PIECES = NPIX * PPR;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int tid = threadIdx.x;
   const i64 n = blockIdx.y;
   const int y0 = (blockIdx.x / tilesX) * 16, x0 = (blockIdx.x % tilesX) * 16;
   const bf16_t *in_n = in + n * (i64)H * W * in_ld;
-  for (int c = tid; c < PIECES; c += 256) {
-    const int pix = c / PPR, part = c % PPR;
-    const int py = pix / HALO, px = pix - py * HALO;
-    const int y = y0 + py - 1, x = x0 + px - 1;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (y >= 0 && y < H && x >= 0 && x < W) v = *reinterpret_cast<const uint4 *>(in_n + ((i64)y * W + x) * in_ld + part * 8);
-    *reinterpret_cast<uint4 *>(lds + pix * PITCH + part * 16) = v;
-  }
-  __syncthreads();
   const int ty = tid >> 4, tx = tid & 15;
   float acc0 = bias ? bias[0] : 0.f, acc1 = 0.f;  // two chains for the dependent dot-product accumulations
+#pragma unroll 1
+  for (int cc = 0; cc < CI; cc += CK) {
+    if (cc) __syncthreads();  // the previous chunk's readers are done
+    for (int c = tid; c < PIECES; c += 256) {
+      const int pix = c / PPR, part = c % PPR;
+      const int py = pix / HALO, px = pix - py * HALO;
+      const int y = y0 + py - 1, x = x0 + px - 1;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (y >= 0 && y < H && x >= 0 && x < W)
+        v = *reinterpret_cast<const uint4 *>(in_n + ((i64)y * W + x) * in_ld + cc + part * 8);
+      *reinterpret_cast<uint4 *>(lds + pix * PITCH + part * 16) = v;
+    }
+    __syncthreads();
 #pragma unroll
-  for (int tap = 0; tap < 9; ++tap) {
-    const unsigned char *row = lds + ((ty + tap / 3) * HALO + tx + tap % 3) * PITCH;
+    for (int tap = 0; tap < 9; ++tap) {
+      const unsigned char *row = lds + ((ty + tap / 3) * HALO + tx + tap % 3) * PITCH;
 #pragma unroll
-    for (int p = 0; p < PPR; ++p) {
-      // operand layout [ci chunk of 32][tap][CoP][32]: row (chunk p/4, tap, co = 0); uniform -> scalar loads
-      const uint32_t *wrow = wt + ((i64)(p / 4) * 9 + tap) * w_tap_stride_dw + (p % 4) * 4;
-      const uint4 v = *reinterpret_cast<const uint4 *>(row + p * 16);
-      acc0 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, v.x), __builtin_bit_cast(bf16x2, wrow[0]), acc0, false);
-      acc1 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, v.y), __builtin_bit_cast(bf16x2, wrow[1]), acc1, false);
-      acc0 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, v.z), __builtin_bit_cast(bf16x2, wrow[2]), acc0, false);
-      acc1 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, v.w), __builtin_bit_cast(bf16x2, wrow[3]), acc1, false);
+      for (int p = 0; p < PPR; ++p) {
+        // operand layout [ci chunk of 32][tap][CoP][32]: row (chunk, tap, co = 0); uniform -> scalar loads
+        const uint32_t *wrow = wt + ((i64)(cc / 32 + p / 4) * 9 + tap) * w_tap_stride_dw + (p % 4) * 4;
+        const uint4 v = *reinterpret_cast<const uint4 *>(row + p * 16);
+        acc0 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, v.x), __builtin_bit_cast(bf16x2, wrow[0]), acc0, false);
+        acc1 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, v.y), __builtin_bit_cast(bf16x2, wrow[1]), acc1, false);
+        acc0 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, v.z), __builtin_bit_cast(bf16x2, wrow[2]), acc0, false);
+        acc1 = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, v.w), __builtin_bit_cast(bf16x2, wrow[3]), acc1, false);
+      }
     }
   }
   const int y = y0 + ty, x = x0 + tx;
@@ -185,49 +193,58 @@ template <int CI>
 __global__ __launch_bounds__(256) void head_wgrad_kernel(const bf16_t *__restrict__ x, int x_ld,
                                                          const float *__restrict__ dz, float *__restrict__ partial,
                                                          int H, int W, int tilesX, int tiles_per_image, int total_tiles) {
-  constexpr int PPR = CI / 8, PITCH = CI * 2 + 16, PIECES = NPIX * PPR;
-  constexpr int CPAIRS = CI / 2, RG = 256 / CPAIRS, ROWS = 16 / RG;  // row groups, tile rows per thread
+  // the halo is staged at most 64 channels at a time (see head_fwd_kernel); a thread keeps the sums of its
+  // channel pair in every chunk
+  constexpr int CK = CI > 64 ? 64 : CI, NCH = CI / CK;
+  constexpr int PPR = CK / 8, PITCH = CK * 2 + 16, PIECES = NPIX * PPR;
+  constexpr int CPAIRS = CK / 2, RG = 256 / CPAIRS, ROWS = 16 / RG;  // row groups, tile rows per thread
   static_assert(256 % CPAIRS == 0 && 16 % RG == 0, "thread split");
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   float *sdz = reinterpret_cast<float *>(lds + NPIX * PITCH);  // [256] dz of the tile (0 outside the image)
   const int tid = threadIdx.x;
   const int cp = tid % CPAIRS, rg = tid / CPAIRS;
-  float acc[9][2];
+  float acc[NCH][9][2];
 #pragma unroll
-  for (int t = 0; t < 9; ++t) acc[t][0] = acc[t][1] = 0.f;
+  for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[ch][t][0] = acc[ch][t][1] = 0.f;
   float dzsum = 0.f;
   for (int tt = blockIdx.x; tt < total_tiles; tt += gridDim.x) {
     const i64 n = tt / tiles_per_image;
     const int r = tt - (int)n * tiles_per_image;
     const int y0 = (r / tilesX) * 16, x0 = (r % tilesX) * 16;
     const bf16_t *x_n = x + n * (i64)H * W * x_ld;
-    __syncthreads();  // the previous tile's readers are done
-    for (int c = tid; c < PIECES; c += 256) {
-      const int pix = c / PPR, part = c % PPR;
-      const int py = pix / HALO, px = pix - py * HALO;
-      const int y = y0 + py - 1, xx = x0 + px - 1;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (y >= 0 && y < H && xx >= 0 && xx < W) v = *reinterpret_cast<const uint4 *>(x_n + ((i64)y * W + xx) * x_ld + part * 8);
-      *reinterpret_cast<uint4 *>(lds + pix * PITCH + part * 16) = v;
-    }
-    {
-      const int y = y0 + (tid >> 4), xx = x0 + (tid & 15);
-      const float d = (y < H && xx < W) ? dz[(n * H + y) * (i64)W + xx] : 0.f;
-      sdz[tid] = d;
-      dzsum += d;
-    }
-    __syncthreads();
-#pragma unroll 1
-    for (int ry = 0; ry < ROWS; ++ry) {
-      const int ty = rg * ROWS + ry;
-#pragma unroll 4
-      for (int tx = 0; tx < 16; ++tx) {
-        const float d = sdz[ty * 16 + tx];
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
-          const uint32_t xv = *reinterpret_cast<const uint32_t *>(lds + ((ty + t / 3) * HALO + tx + t % 3) * PITCH + cp * 4);
-          acc[t][0] = fmaf(bf16_to_f32(xv & 0xffffu), d, acc[t][0]);
-          acc[t][1] = fmaf(bf16_to_f32(xv >> 16), d, acc[t][1]);
+    for (int ch = 0; ch < NCH; ++ch) {
+      __syncthreads();  // the previous tile's / chunk's readers are done
+      for (int c = tid; c < PIECES; c += 256) {
+        const int pix = c / PPR, part = c % PPR;
+        const int py = pix / HALO, px = pix - py * HALO;
+        const int y = y0 + py - 1, xx = x0 + px - 1;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (y >= 0 && y < H && xx >= 0 && xx < W)
+          v = *reinterpret_cast<const uint4 *>(x_n + ((i64)y * W + xx) * x_ld + ch * CK + part * 8);
+        *reinterpret_cast<uint4 *>(lds + pix * PITCH + part * 16) = v;
+      }
+      if (ch == 0) {
+        const int y = y0 + (tid >> 4), xx = x0 + (tid & 15);
+        const float d = (y < H && xx < W) ? dz[(n * H + y) * (i64)W + xx] : 0.f;
+        sdz[tid] = d;
+        dzsum += d;
+      }
+      __syncthreads();
+#pragma unroll 1
+      for (int ry = 0; ry < ROWS; ++ry) {
+        const int ty = rg * ROWS + ry;
+#pragma unroll 4
+        for (int tx = 0; tx < 16; ++tx) {
+          const float d = sdz[ty * 16 + tx];
+#pragma unroll
+          for (int t = 0; t < 9; ++t) {
+            const uint32_t xv = *reinterpret_cast<const uint32_t *>(lds + ((ty + t / 3) * HALO + tx + t % 3) * PITCH + cp * 4);
+            acc[ch][t][0] = fmaf(bf16_to_f32(xv & 0xffffu), d, acc[ch][t][0]);
+            acc[ch][t][1] = fmaf(bf16_to_f32(xv >> 16), d, acc[ch][t][1]);
+          }
         }
       }
     }
@@ -236,10 +253,12 @@ __global__ __launch_bounds__(256) void head_wgrad_kernel(const bf16_t *__restric
   __syncthreads();
   float *red = reinterpret_cast<float *>(lds);  // [RG][CI*9]
 #pragma unroll
-  for (int t = 0; t < 9; ++t) {
-    red[rg * (CI * 9) + (cp * 2) * 9 + t] = acc[t][0];
-    red[rg * (CI * 9) + (cp * 2 + 1) * 9 + t] = acc[t][1];
-  }
+  for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      red[rg * (CI * 9) + (ch * CK + cp * 2) * 9 + t] = acc[ch][t][0];
+      red[rg * (CI * 9) + (ch * CK + cp * 2 + 1) * 9 + t] = acc[ch][t][1];
+    }
   __shared__ float wred[4];
   float s1[1] = {dzsum};
   block_sum<1>(s1, wred);  // contains the barrier that publishes `red`
@@ -300,7 +319,7 @@ int unet_conv3x3_head_bf16(const uint16_t *in, int in_ld, const uint16_t *w_pack
   UNET_REQUIRE((((uintptr_t)in | (uintptr_t)w_packed) & 15) == 0, "unet_conv3x3_head_bf16: pointers must be 16-byte aligned");
   UNET_REQUIRE((i64)H * W * in_ld < (1ll << 31), "unet_conv3x3_head_bf16: one image must stay below 2^31 elements");
   const int tilesX = (W + 15) / 16, tiles = tilesX * ((H + 15) / 16);
-  const size_t lds = (size_t)NPIX * (CiP * 2 + 16);
+  const size_t lds = (size_t)NPIX * ((CiP > 64 ? 64 : CiP) * 2 + 16);
   const uint32_t *wt = reinterpret_cast<const uint32_t *>(w_packed);
   const int tap_stride = CoP * 32 / 2;  // dwords between consecutive (chunk, tap) rows
   ProfScope prof(PROF_CONV_HEAD_BF16, 2.0 * N * H * W * (double)CiP * 9, (double)N * H * W * (2.0 * CiP + 4.0), as_stream(s));
@@ -374,8 +393,9 @@ int unet_conv3x3_head_wgrad_bf16(const float *dz, const uint16_t *x, int x_ld, f
   int rc = unet_workspace(&ws, sizeof(float) * (size_t)blocks * row_len, as_stream(s));
   if (rc) return rc;
   float *partial = (float *)ws;
-  const size_t lds_main = (size_t)NPIX * (CiP * 2 + 16) + 256 * sizeof(float);
-  const size_t lds_red = sizeof(float) * (size_t)(256 / (CiP / 2)) * CiP * 9;
+  const int ck = CiP > 64 ? 64 : CiP;  // channels staged at a time
+  const size_t lds_main = (size_t)NPIX * (ck * 2 + 16) + 256 * sizeof(float);
+  const size_t lds_red = sizeof(float) * (size_t)(256 / (ck / 2)) * CiP * 9;
   const size_t lds = lds_main > lds_red ? lds_main : lds_red;
   ProfScope prof(PROF_CONV_HEAD_BF16, 2.0 * N * H * W * (double)CiP * 9, (double)N * H * W * (2.0 * CiP + 4.0), as_stream(s));
   static bool done32[64], done64[64], done128[64];

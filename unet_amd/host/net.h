@@ -940,8 +940,7 @@ class Net {
           if (n.c1 % 32 || n.c2 % 32 || n.concat_child >= 0 || is_final) return why = "a concat with channel counts off multiples of 32", false;
           break;
         case ATTENTION_LAYER:
-          // the gate itself runs on the fp32 kernels between two layout conversions; everything around it
-          // stays NHWC bf16
+          // the gate's projections run in fp32 inside unet_attention_bf16; its tensors stay NHWC bf16
           if (n.c1 % 32 || n.c2 % 32 || is_final) return why = "an attention gate with channel counts off multiples of 32", false;
           break;
         default:
@@ -984,13 +983,6 @@ class Net {
         const size_t cells = b * (size_t)(n.in_h / 2) * (n.in_w / 2);
         n.z.ensure(sizeof(float) * cells * n.att_ci());  // int_1
         n.bn.ensure(sizeof(float) * cells);              // int_2 (the coefficients)
-        att_x_.ensure(sizeof(float) * pix * n.c1);
-        att_o_.ensure(sizeof(float) * pix * n.c1);
-        att_dx_.ensure(sizeof(float) * pix * n.c1);
-        att_g_.ensure(sizeof(float) * cells * n.c2);
-        att_dg_.ensure(sizeof(float) * cells * n.c2);
-        att_g1_.ensure(sizeof(float) * cells * n.att_ci());
-        att_g2_.ensure(sizeof(float) * cells);
       }
       if (n.narrow) {  // fp32 side buffers of the final layer
         const size_t fb = sizeof(float) * b * (size_t)n.out_elems();
@@ -1140,13 +1132,12 @@ class Net {
       case CONCAT_LAYER:
         break;  // both parents already wrote their slices of this layer's buffer
       case ATTENTION_LAYER: {
-        // NHWC bf16 -> NCHW fp32, the fp32 gate, and back into this layer's (slice of a concat) buffer
+        // x, g and the output stay NHWC bf16 (the output may be a slice of a concat buffer); the projections
+        // run in fp32 inside the call
         const Node &x = nodes_[n.parents[0]], &g = nodes_[n.parents[1]];
-        UNET_CALL(unet_nhwc_bf16_to_nchw_f32(x.y_ptr, att_x_.f32(), batch, n.c1, n.in_h, n.in_w, x.y_ld, stream_));
-        UNET_CALL(unet_nhwc_bf16_to_nchw_f32(g.y_ptr, att_g_.f32(), batch, n.c2, n.in_h / 2, n.in_w / 2, g.y_ld, stream_));
-        UNET_CALL(unet_attention_f32(n.z.f32(), n.bn.f32(), att_o_.f32(), params_.f32() + n.param_off, att_x_.f32(),
-                                     att_g_.f32(), batch, n.in_h, n.in_w, n.c1, n.c2, n.att_ci(), stream_));
-        UNET_CALL(unet_nchw_f32_to_nhwc_bf16(att_o_.f32(), n.y_ptr, batch, n.out_c, n.out_h, n.out_w, n.y_ld, n.cop, stream_));
+        UNET_CALL(unet_attention_bf16(x.y_ptr, x.y_ld, g.y_ptr, g.y_ld, params_.f32() + n.param_off, n.z.f32(),
+                                      n.bn.f32(), n.y_ptr, n.y_ld, batch, n.in_h, n.in_w, n.c1, n.c2, n.att_ci(),
+                                      stream_));
         break;
       }
       default:
@@ -1309,30 +1300,16 @@ class Net {
       case ATTENTION_LAYER: {
         const uint16_t *d1 = n.g_written ? n.gb.u16() : n.g2_ptr;
         const int l1 = n.g_written ? n.cop : n.g2_ld;
+        const uint16_t *d2 = (n.g_written && n.g2_ptr) ? n.g2_ptr : nullptr;
         if (!d1) return;  // not on a path to the loss
         Node &x = nodes_[n.parents[0]], &g = nodes_[n.parents[1]];
-        const int hg = n.in_h / 2, wg = n.in_w / 2;
-        float *dy = att_o_.f32();  // the forward output is not needed any more
-        UNET_CALL(unet_nhwc_bf16_to_nchw_f32(d1, dy, batch, n.out_c, n.out_h, n.out_w, l1, stream_));
-        if (n.g_written && n.g2_ptr) {  // two consumers: add the concat slice's gradient
-          UNET_CALL(unet_nhwc_bf16_to_nchw_f32(n.g2_ptr, att_dx_.f32(), batch, n.out_c, n.out_h, n.out_w, n.g2_ld, stream_));
-          UNET_CALL(unet_add_b_to_a_f32(dy, att_dx_.f32(), (int64_t)batch * n.out_elems(), stream_));
-        }
-        UNET_CALL(unet_nhwc_bf16_to_nchw_f32(x.y_ptr, att_x_.f32(), batch, n.c1, n.in_h, n.in_w, x.y_ld, stream_));
-        UNET_CALL(unet_nhwc_bf16_to_nchw_f32(g.y_ptr, att_g_.f32(), batch, n.c2, hg, wg, g.y_ld, stream_));
-        UNET_CALL(unet_attention_backward_f32(dy, n.z.f32(), n.bn.f32(), att_x_.f32(), att_g_.f32(),
-                                              params_.f32() + n.param_off, att_g1_.f32(), att_g2_.f32(), att_dx_.f32(),
-                                              att_dg_.f32(), grads_.f32() + n.param_off, batch, n.in_h, n.in_w, n.c1,
-                                              n.c2, n.att_ci(), stream_));
-        auto deliver = [&](Node &p, const float *src, int c, int h, int w) {
-          if (p.g_written)
-            UNET_CALL(unet_nchw_f32_add_to_nhwc_bf16(src, p.gb.u16(), batch, c, h, w, p.cop, stream_));
-          else
-            UNET_CALL(unet_nchw_f32_to_nhwc_bf16(src, p.gb.u16(), batch, c, h, w, p.cop, p.cop, stream_));
-          p.g_written = true;
-        };
-        deliver(x, att_dx_.f32(), n.c1, n.in_h, n.in_w);
-        deliver(g, att_dg_.f32(), n.c2, hg, wg);
+        UNET_CALL(unet_attention_backward_bf16(d1, l1, d2, n.g2_ld, x.y_ptr, x.y_ld, g.y_ptr, g.y_ld,
+                                               params_.f32() + n.param_off, n.z.f32(), n.bn.f32(), x.gb.u16(), x.cop,
+                                               x.g_written ? 1 : 0, g.gb.u16(), g.cop, g.g_written ? 1 : 0,
+                                               grads_.f32() + n.param_off, batch, n.in_h, n.in_w, n.c1, n.c2,
+                                               n.att_ci(), stream_));
+        x.g_written = true;
+        g.g_written = true;
         break;
       }
       default:
@@ -1372,8 +1349,6 @@ class Net {
   bool use_bf16_ = false;
   DeviceBuffer x16_;      // network input as NHWC bf16, channels padded to in_cp()
   DeviceBuffer dz16_;     // scratch: gradient w.r.t. a layer's pre-BN output
-  // scratch of the attention gates on the bf16 path (fp32 NCHW): x, g, output / incoming gradient, gradients
-  DeviceBuffer att_x_, att_g_, att_o_, att_dx_, att_dg_, att_g1_, att_g2_;
   bool verbose_ = true;
   unet_stream_t stream_ = nullptr;
   int64_t bucket_bytes_ = 8 << 20;
