@@ -39,14 +39,25 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const bf16_t *__restrict_
 #pragma unroll 1
   for (int cc = 0; cc < CI; cc += CK) {
     if (cc) __syncthreads();  // the previous chunk's readers are done
-    for (int c = tid; c < PIECES; c += 256) {
-      const int pix = c / PPR, part = c % PPR;
-      const int py = pix / HALO, px = pix - py * HALO;
-      const int y = y0 + py - 1, x = x0 + px - 1;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (y >= 0 && y < H && x >= 0 && x < W)
-        v = *reinterpret_cast<const uint4 *>(in_n + ((i64)y * W + x) * in_ld + cc + part * 8);
-      *reinterpret_cast<uint4 *>(lds + pix * PITCH + part * 16) = v;
+    {
+      // all of a thread's pieces are requested before the first one is stored: one memory latency per chunk
+      constexpr int TRIPS = (PIECES + 255) / 256;
+      uint4 v[TRIPS];
+#pragma unroll
+      for (int i = 0; i < TRIPS; ++i) {
+        const int c = tid + i * 256;
+        const int pix = c / PPR, part = c % PPR;
+        const int py = pix / HALO, px = pix - py * HALO;
+        const int y = y0 + py - 1, x = x0 + px - 1;
+        v[i] = make_uint4(0, 0, 0, 0);
+        if (c < PIECES && y >= 0 && y < H && x >= 0 && x < W)
+          v[i] = *reinterpret_cast<const uint4 *>(in_n + ((i64)y * W + x) * in_ld + cc + part * 8);
+      }
+#pragma unroll
+      for (int i = 0; i < TRIPS; ++i) {
+        const int c = tid + i * 256;
+        if (c < PIECES) *reinterpret_cast<uint4 *>(lds + (c / PPR) * PITCH + (c % PPR) * 16) = v[i];
+      }
     }
     __syncthreads();
 #pragma unroll
@@ -217,14 +228,25 @@ __global__ __launch_bounds__(256) void head_wgrad_kernel(const bf16_t *__restric
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
       __syncthreads();  // the previous tile's / chunk's readers are done
-      for (int c = tid; c < PIECES; c += 256) {
-        const int pix = c / PPR, part = c % PPR;
-        const int py = pix / HALO, px = pix - py * HALO;
-        const int y = y0 + py - 1, xx = x0 + px - 1;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (y >= 0 && y < H && xx >= 0 && xx < W)
-          v = *reinterpret_cast<const uint4 *>(x_n + ((i64)y * W + xx) * x_ld + ch * CK + part * 8);
-        *reinterpret_cast<uint4 *>(lds + pix * PITCH + part * 16) = v;
+      {
+        // all of a thread's pieces are requested before the first one is stored
+        constexpr int TRIPS = (PIECES + 255) / 256;
+        uint4 v[TRIPS];
+#pragma unroll
+        for (int i = 0; i < TRIPS; ++i) {
+          const int c = tid + i * 256;
+          const int pix = c / PPR, part = c % PPR;
+          const int py = pix / HALO, px = pix - py * HALO;
+          const int y = y0 + py - 1, xx = x0 + px - 1;
+          v[i] = make_uint4(0, 0, 0, 0);
+          if (c < PIECES && y >= 0 && y < H && xx >= 0 && xx < W)
+            v[i] = *reinterpret_cast<const uint4 *>(x_n + ((i64)y * W + xx) * x_ld + ch * CK + part * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < TRIPS; ++i) {
+          const int c = tid + i * 256;
+          if (c < PIECES) *reinterpret_cast<uint4 *>(lds + (c / PPR) * PITCH + (c % PPR) * 16) = v[i];
+        }
       }
       if (ch == 0) {
         const int y = y0 + (tid >> 4), xx = x0 + (tid & 15);
