@@ -67,7 +67,57 @@ __device__ __forceinline__ float gate_input(const GateCell &c, int k) {
   return k < c.Cx ? c.xp[k * c.xplane] : c.gp[(k - c.Cx) * c.gplane];
 }
 
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
 // ---- forward ---------------------------------------------------------------------------------
+// The projections on the matrix cores (v_mfma_f32_32x32x2_f32: fp32 operands and accumulator), for Ci a
+// multiple of 32 and K a multiple of 16.  One wavefront owns 32 consecutive cells; per 32 intermediate
+// channels it accumulates D[o][cell] += W[k][o] * in[k][cell] two input channels at a time: lane l supplies
+// W[k + l/32][o0 + l%32] (a 128-byte row of the weights) and in[k + l/32][cell l%32] (128 bytes of a plane),
+// eight such steps with their sixteen loads in flight per trip.  Accumulator register r of lane l is
+// (o = o0 + 8*(r/4) + 4*(l/32) + r%4, cell l%32), so the int_1 stores are coalesced over the cells.
+__global__ __launch_bounds__(256) void attn_gate_fwd_mfma_kernel(GateIn in, const float *__restrict__ params, int Ci,
+                                                                 float *__restrict__ int1, float *__restrict__ alpha,
+                                                                 i64 cells) {
+  const int K = in.Cx + in.Cg;
+  const float *psi = params + (i64)K * Ci, *b1 = psi + Ci;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 31, half = lane >> 5;
+  const i64 cell = ((i64)blockIdx.x * 4 + wave) * 32 + j;
+  const bool live = cell < cells;
+  const i64 hw = (i64)in.Hg * in.Wg;
+  const i64 n = live ? cell / hw : 0;
+  const int rem = live ? (int)(cell - n * hw) : 0;
+  const int h = rem / in.Wg, w = rem - h * in.Wg;
+  const GateCell gc = gate_cell(in, n, h, w);
+  float z = 0.f;
+  for (int o0 = 0; o0 < Ci; o0 += 32) {
+    floatx16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int kb = 0; kb < K; kb += 16) {
+      float a[8], b[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int k = kb + 2 * u + half;
+        a[u] = params[(i64)k * Ci + o0 + j];
+        b[u] = live ? gate_input(gc, k) : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int o = o0 + 8 * (r >> 2) + 4 * half + (r & 3);
+      const float t = acc[r] + b1[o];
+      const float v = t > 0.f ? t : 0.f;
+      if (live) int1[(n * Ci + o) * hw + rem] = v;
+      z = fmaf(v, psi[o], z);
+    }
+  }
+  z += __shfl_xor(z, 32, 64);  // the two halves hold the other sixteen channels of the same cell
+  if (half == 0 && live) alpha[cell] = 1.0f / (1.0f + expf(-(b1[Ci] + z)));
+}
+
 // 256 threads = 64 consecutive cells x 4 channel groups; a thread walks its group's intermediate
 // channels eight at a time (the weights of a group are uniform over a wavefront).  The psi dot
 // product is summed over the four groups through LDS in group order.
@@ -290,12 +340,68 @@ __global__ __launch_bounds__(256) void attn_gate_dgrad_kernel(const float *__res
   }
 }
 
+// wt[o][k] = W[k][o]: the input-gradient kernel below reads the weights with k across the lanes
+__global__ __launch_bounds__(256) void attn_transpose_w_kernel(const float *__restrict__ params, int K, int Ci,
+                                                               float *__restrict__ wt) {
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < K * Ci; e += gridDim.x * blockDim.x) {
+    const int o = e / K, k = e - o * K;
+    wt[e] = params[(i64)k * Ci + o];
+  }
+}
+
+// The input gradients on the matrix cores, for K a multiple of 32 and Ci a multiple of 16: one wavefront
+// owns 32 cells; per 32 input channels D[k][cell] += W[k][o] * gpre[o][cell], two intermediate channels at a
+// time (lane l supplies wt[o + l/32][k0 + l%32] and gpre[o + l/32][cell l%32]).  Outputs as in the kernel above.
+__global__ __launch_bounds__(256) void attn_gate_dgrad_mfma_kernel(const float *__restrict__ gpre,
+                                                                   const float *__restrict__ wt, int Ci, int Cx,
+                                                                   int Cg, int Hg, int Wg, float *__restrict__ grad_x,
+                                                                   float *__restrict__ grad_g, i64 cells,
+                                                                   int x_dense) {
+  const int K = Cx + Cg;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 31, half = lane >> 5;
+  const i64 cell = ((i64)blockIdx.x * 4 + wave) * 32 + j;
+  const bool live = cell < cells;
+  const i64 hw = (i64)Hg * Wg;
+  const i64 n = live ? cell / hw : 0;
+  const int rem = live ? (int)(cell - n * hw) : 0;
+  const int h = rem / Wg, w = rem - h * Wg;
+  const float *gp = gpre + n * Ci * hw + rem;
+  for (int k0 = 0; k0 < K; k0 += 32) {
+    floatx16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int ob = 0; ob < Ci; ob += 16) {
+      float a[8], b[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int o = ob + 2 * u + half;
+        a[u] = wt[(i64)o * K + k0 + j];
+        b[u] = live ? gp[o * hw] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u], acc, 0, 0, 0);
+    }
+    if (!live) continue;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int k = k0 + 8 * (r >> 2) + 4 * half + (r & 3);
+      if (k < Cx) {
+        if (x_dense)
+          grad_x[((n * Cx + k) * Hg + h) * (i64)Wg + w] = acc[r];
+        else
+          grad_x[((n * Cx + k) * (2 * Hg) + 2 * h) * (i64)(2 * Wg) + 2 * w] += acc[r];
+      } else {
+        grad_g[((n * Cg + (k - Cx)) * Hg + h) * (i64)Wg + w] = acc[r];
+      }
+    }
+  }
+}
+
 // Weight gradient of the projections: dW[k][o] = sum_cells in[k] * gpre[o], a GEMM whose reduction runs
 // over the cells.  A workgroup owns a 32(k) x 32(o) tile over a slice of the cells, staged 64 cells at a
 // time through LDS; each of its four wavefronts multiplies a quarter of the staged cells with
 // v_mfma_f32_32x32x2_f32 (fp32 operands and accumulator) and the four accumulators are added in
 // wavefront order at the end.  part[split][K][Ci].
-typedef float floatx16 __attribute__((ext_vector_type(16)));
 __global__ __launch_bounds__(256) void attn_wgrad_kernel(GateIn in, const float *__restrict__ gpre, int Ci,
                                                          float *__restrict__ part, i64 cells, i64 cells_per_split) {
   constexpr int PITCH = CELLS + 1;
@@ -556,6 +662,22 @@ __global__ __launch_bounds__(256) void attn_apply_bwd_bf16_kernel(const bf16_t *
   }
 }
 
+int launch_gate_fwd(const GateIn &in, const float *weights, int Ci, float *int1, float *alpha, i64 cells,
+                    hipStream_t st) {
+  const int K = in.Cx + in.Cg;
+  if (Ci % 32 == 0 && K % 16 == 0)
+    hipLaunchKernelGGL(attn_gate_fwd_mfma_kernel, dim3(cdiv_u(cells, 128)), dim3(256), 0, st, in, weights, Ci, int1,
+                       alpha, cells);
+  else if (Ci % 32 == 0 && K % 8 == 0)
+    hipLaunchKernelGGL(attn_gate_fwd_kernel<true>, dim3(cdiv_u(cells, CELLS)), dim3(256), 0, st, in, weights, Ci, int1,
+                       alpha, cells);
+  else
+    hipLaunchKernelGGL(attn_gate_fwd_kernel<false>, dim3(cdiv_u(cells, CELLS)), dim3(256), 0, st, in, weights, Ci,
+                       int1, alpha, cells);
+  UNET_LAUNCH_CHECK("attn_gate_fwd_kernel");
+  return UNET_OK;
+}
+
 int check_attention_shape(const char *who, int batch, int H_x, int W_x, int Cx, int Cg, int Ci) {
   UNET_REQUIRE(batch > 0 && H_x >= 2 && W_x >= 2 && H_x % 2 == 0 && W_x % 2 == 0 && Cx > 0 && Cg > 0 && Ci > 0,
                "%s: need batch, channel counts > 0 and even H_x, W_x >= 2 (g is half the size of x)", who);
@@ -581,14 +703,8 @@ int unet_attention_f32(float *activations_int_1, float *activations_int_2, float
   const int Hg = H_x / 2, Wg = W_x / 2;
   const i64 cells = (i64)batch_size * Hg * Wg, pixels = 4 * cells;
   const GateIn in{input_x, input_g, channels_in_x, channels_in_g, Hg, Wg, 0};
-  const bool full = int_channels % 32 == 0 && (channels_in_x + channels_in_g) % 8 == 0;
-  if (full)
-    hipLaunchKernelGGL(attn_gate_fwd_kernel<true>, dim3(cdiv_u(cells, CELLS)), dim3(256), 0, as_stream(s), in, weights,
-                       int_channels, activations_int_1, activations_int_2, cells);
-  else
-    hipLaunchKernelGGL(attn_gate_fwd_kernel<false>, dim3(cdiv_u(cells, CELLS)), dim3(256), 0, as_stream(s), in, weights,
-                       int_channels, activations_int_1, activations_int_2, cells);
-  UNET_LAUNCH_CHECK("attn_gate_fwd_kernel");
+  rc = launch_gate_fwd(in, weights, int_channels, activations_int_1, activations_int_2, cells, as_stream(s));
+  if (rc) return rc;
   hipLaunchKernelGGL(attn_resample_mul_kernel, dim3(ew_grid(pixels)), dim3(256), 0, as_stream(s), input_x,
                      (const float *)activations_int_2, activations, channels_in_x, H_x, W_x, pixels);
   UNET_LAUNCH_CHECK("attn_resample_mul_kernel");
@@ -635,7 +751,13 @@ static int attention_backward_core(const AttnPlan &pl, const float *sbuf, const 
   hipLaunchKernelGGL(attn_cell_bwd_kernel, dim3(ew_grid(cells)), dim3(256), 0, st, sbuf, alpha, int1, psi, galpha,
                      gpre, Ci, H_x, W_x, cells);
   UNET_LAUNCH_CHECK("attn_cell_bwd_kernel");
-  if (K % 32 == 0 && Ci % 8 == 0)
+  if (K % 32 == 0 && Ci % 16 == 0) {
+    // part (the weight-gradient partials, at least K*Ci floats) is free until the weight-gradient kernel runs
+    hipLaunchKernelGGL(attn_transpose_w_kernel, dim3(ew_grid((i64)K * Ci)), dim3(256), 0, st, weights, K, Ci, part);
+    UNET_LAUNCH_CHECK("attn_transpose_w_kernel");
+    hipLaunchKernelGGL(attn_gate_dgrad_mfma_kernel, dim3(cdiv_u(cells, 128)), dim3(256), 0, st, (const float *)gpre,
+                       (const float *)part, Ci, Cx, Cg, Hg, Wg, grad_x, grad_g, cells, in.x_dense);
+  } else if (K % 32 == 0 && Ci % 8 == 0)
     hipLaunchKernelGGL(attn_gate_dgrad_kernel<true>, dim3(cdiv_u(cells, CELLS)), dim3(256), 0, st, (const float *)gpre,
                        weights, Ci, Cx, Cg, Hg, Wg, grad_x, grad_g, cells, in.x_dense);
   else
@@ -716,13 +838,8 @@ int unet_attention_bf16(const uint16_t *x, int x_ld, const uint16_t *g, int g_ld
   rc = unet_nhwc_bf16_to_nchw_f32(g, gf, batch_size, Cg, Hg, Wg, g_ld, s);
   if (rc) return rc;
   const GateIn in{xs, gf, Cx, Cg, Hg, Wg, 1};
-  if (Ci % 32 == 0 && (Cx + Cg) % 8 == 0)
-    hipLaunchKernelGGL(attn_gate_fwd_kernel<true>, dim3(cdiv_u(cells, CELLS)), dim3(256), 0, as_stream(s), in, weights,
-                       Ci, activations_int_1, activations_int_2, cells);
-  else
-    hipLaunchKernelGGL(attn_gate_fwd_kernel<false>, dim3(cdiv_u(cells, CELLS)), dim3(256), 0, as_stream(s), in, weights,
-                       Ci, activations_int_1, activations_int_2, cells);
-  UNET_LAUNCH_CHECK("attn_gate_fwd_kernel");
+  rc = launch_gate_fwd(in, weights, Ci, activations_int_1, activations_int_2, cells, as_stream(s));
+  if (rc) return rc;
   const i64 total = pixels * (Cx / 8);
   hipLaunchKernelGGL(attn_apply_bf16_kernel, dim3(ew_grid(total)), dim3(256), 0, as_stream(s), x, x_ld,
                      (const float *)activations_int_2, out, out_ld, Cx / 8, H_x, W_x, total);
