@@ -216,7 +216,16 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restri
     float s = 0.f;
     if (ci < Ci) {
       const float *p = partial + ((i64)t * CoP + co) * CiP + ci;
-      for (int k = grp; k < splits; k += 8) s += p[k * slice];
+      int k = grp;
+      // eight slices per trip: their loads are in flight together (the order of the additions stays k ascending)
+      for (; k + 56 < splits; k += 64) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = p[(k + 8 * u) * slice];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+      }
+      for (; k < splits; k += 8) s += p[k * slice];
     }
     red[grp][lane32] = s;
     __syncthreads();
@@ -246,7 +255,20 @@ __global__ __launch_bounds__(256) void wgrad_reduce_tile_kernel(const float *__r
     float s = 0.f;
     if (ci < Ci && co < Co) {
       const float *p = partial + ((i64)t * CoP + co) * CiP + ci;
-      for (int k = 0; k < splits; ++k) s += p[k * slice];
+      int k = 0;
+      for (; k + 7 < splits; k += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = p[(k + u) * slice];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+      }
+      for (; k + 1 < splits; k += 2) {
+        const float v0 = p[k * slice], v1 = p[(k + 1) * slice];
+        s += v0;
+        s += v1;
+      }
+      for (; k < splits; ++k) s += p[k * slice];
     }
     tile[lane32][grp * taps + t] = s;
   }
