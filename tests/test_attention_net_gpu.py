@@ -172,3 +172,24 @@ def test_attention_unet_on_the_bf16_path_matches_the_bf16_storage_oracle(nn):
     # inference (running statistics, BN + ReLU folded into the conv epilogues) runs through the gates too
     y = net.forward(x[:2], True)
     assert y.shape[-2:] == (32, 48) and np.isfinite(y).all()
+
+
+def test_attention_unet_checkpoint_round_trip(nn, tmp_path):
+    """save() / load() of a network with attention gates (layers with weights but no batch norm): a restored
+    network continues training with the same bits."""
+    from unet_amd import checkpoint
+    graph = torch_ref.attention_unet_graph(16, 16, 3, 32)
+    rng = np.random.default_rng(2)
+    x = rng.standard_normal((2, 3, 16, 16)).astype(np.float32)
+    m = (rng.random((2, 16, 16)) < 0.3).astype(np.float32)
+    net = make(nn, graph)
+    for _ in range(3):
+        net.train_step(x, m, 1e-2, True)
+    path = str(tmp_path / "attn.npz")
+    checkpoint.save(net, path)
+    net2 = make(nn, graph)
+    checkpoint.load(net2, path)
+    np.testing.assert_array_equal(net2.get_parameters(), net.get_parameters())
+    a, b = net.train_step(x, m, 1e-2, True), net2.train_step(x, m, 1e-2, True)
+    assert a == b
+    np.testing.assert_array_equal(net2.get_parameters(), net.get_parameters())
