@@ -121,7 +121,8 @@ struct Node {
   const uint16_t *g2_ptr = nullptr;  // second gradient source: this layer's slice of a concat's gradient
   int g2_ld = 0;
   DeviceBuffer mask;             // max pool tie mask
-  DeviceBuffer coef;             // batch-norm coefficients of the last forward
+  DeviceBuffer coef;             // batch-norm coefficients of the last training forward
+  DeviceBuffer coef_inf;         // the same from the running statistics (inference), valid while Net::inf_coef_valid_
   DeviceBuffer w_fwd, w_bwd;     // packed bf16 weights
   DeviceBuffer stat_partials;
   DeviceBuffer bwd_partials;     // BN-backward sums emitted by the consumer's data-gradient kernel
@@ -248,6 +249,7 @@ class Net {
       UNET_CALL(unet_memset(n.running.raw(), 0, sizeof(float), stream_));
     }
     params_dirty_ = true;
+    inf_coef_valid_ = false;
     pack_boxes_ = 0;
   }
 
@@ -259,6 +261,17 @@ class Net {
     ensure_batch(batch);
     if (use_bf16_) {
       if (params_dirty_) pack_all_weights();
+      if (!inference) {
+        inf_coef_valid_ = false;  // a training forward moves the running statistics
+      } else if (!inf_coef_valid_) {
+        // inference coefficients depend on gamma/beta and the running statistics only: computed when those
+        // changed, not per forward (22 launches of a 52-launch batch-1 forward otherwise)
+        for (Node &n : nodes_)
+          if (n.has_params() && !n.narrow)
+            UNET_CALL(unet_bn_inference_coef_bf16(params_.f32() + n.param_off + n.num_wb, n.running.f32(), n.out_c, n.cop,
+                                                  n.coef_inf.f32(), stream_));
+        inf_coef_valid_ = true;
+      }
       UNET_CALL(unet_nchw_f32_to_nhwc_bf16(images, x16_.u16(), batch, in_c_, in_h_, in_w_, in_cp(), in_cp(), stream_));
       for (Node &n : nodes_) forward_node_bf16(n, batch, inference);
       return;
@@ -312,6 +325,7 @@ class Net {
     UNET_CALL(unet_update_weights_adam_f32(params_.f32(), grads_.f32(), adam_.f32(), learning_rate,
                                            total_params_, step_count_, stream_));
     params_dirty_ = true;
+    inf_coef_valid_ = false;
   }
 
   // ---- host-facing helpers ----------------------------------------------------
@@ -469,6 +483,7 @@ class Net {
     UNET_CALL(unet_memcpy_h2d(params_.raw(), src, sizeof(float) * (size_t)total_params_, stream_));
     sync();
     params_dirty_ = true;
+    inf_coef_valid_ = false;
   }
   void copy_grads_to_host(float *dst) {
     UNET_CALL(unet_memcpy_d2h(dst, grads_.raw(), sizeof(float) * (size_t)total_params_, 1, stream_));
@@ -492,6 +507,7 @@ class Net {
     const Node &n = nodes_.at(layer);
     UNET_CALL(unet_memcpy_h2d(n.running.raw(), src, sizeof(float) * (size_t)n.num_bn, stream_));
     sync();
+    inf_coef_valid_ = false;
   }
   // Adam state ([m,v] interleaved per parameter) and step count, for checkpoints.
   void copy_optimizer_state_to_host(float *dst) {
@@ -969,6 +985,7 @@ class Net {
       if (n.has_params()) {
         n.zb.ensure(2 * pix * n.cop);
         n.coef.ensure(sizeof(float) * (size_t)unet_bn_coef_floats(n.cop));
+        n.coef_inf.ensure(sizeof(float) * (size_t)unet_bn_coef_floats(n.cop));
         const size_t in_pix_tiles = (size_t)unet_conv3x3_stat_tiles(n.in_h, n.in_w);
         const size_t parts = n.type == CONV_LAYER ? b * in_pix_tiles : 4 * b * in_pix_tiles;
         n.stat_partials.ensure(sizeof(float) * parts * n.cop * 2);
@@ -1016,6 +1033,7 @@ class Net {
     in_masks_.ensure(sizeof(float) * b * (size_t)f.out_h * f.out_w);
     loss_values_.ensure(sizeof(float) * 3 * b);
     params_dirty_ = true;
+    inf_coef_valid_ = false;
     pack_boxes_ = 0;
   }
 
@@ -1063,12 +1081,11 @@ class Net {
         const bool fold_bn = inference && !n.narrow && !(n.type == CONV_LAYER && n.activation == SIGMOID);
         if (fold_bn) {
           // inference: BN (running statistics) + ReLU folded into the conv epilogue, straight into y
-          UNET_CALL(unet_bn_inference_coef_bf16(gb, n.running.f32(), n.out_c, n.cop, n.coef.f32(), stream_));
           if (n.type == CONV_LAYER)
-            UNET_CALL(unet_conv3x3_bn_relu_bf16(in, in_ld, n.w_fwd.u16(), bias, n.out_c, n.coef.f32(), n.y_ptr, n.y_ld, batch,
+            UNET_CALL(unet_conv3x3_bn_relu_bf16(in, in_ld, n.w_fwd.u16(), bias, n.out_c, n.coef_inf.f32(), n.y_ptr, n.y_ld, batch,
                                                 n.in_h, n.in_w, in_cip, n.cop, stream_));
           else
-            UNET_CALL(unet_tconv2x2_bn_relu_bf16(in, in_ld, n.w_fwd.u16(), bias, n.out_c, n.coef.f32(), n.y_ptr, n.y_ld, batch,
+            UNET_CALL(unet_tconv2x2_bn_relu_bf16(in, in_ld, n.w_fwd.u16(), bias, n.out_c, n.coef_inf.f32(), n.y_ptr, n.y_ld, batch,
                                                  n.in_h, n.in_w, n.cip, n.cop, stream_));
           break;
         }
@@ -1102,21 +1119,20 @@ class Net {
             UNET_CALL(unet_relu_f32(n.bn.f32(), n.act.f32(), out_n, stream_));
           break;
         }
-        if (inference)
-          UNET_CALL(unet_bn_inference_coef_bf16(gb, n.running.f32(), n.out_c, n.cop, n.coef.f32(), stream_));
-        else
+        if (!inference)
           UNET_CALL(unet_bn_finalize_bf16(parts, num_parts, n.out_c, n.cop, out_pix, gb, n.batch_stats.f32(),
                                           n.running.f32(), n.coef.f32(), stream_));
+        const float *coef = inference ? n.coef_inf.f32() : n.coef.f32();
         const int act = (n.type == CONV_LAYER && n.activation == SIGMOID) ? 1 : 0;
         if (n.pool_child >= 0) {
           // the skip layers of the encoder: activation, pooled activation and tie mask from one pass over z
           Node &q = nodes_[n.pool_child];
-          UNET_CALL(unet_bn_act_pool_bf16(n.zb.u16(), n.cop, n.y_ptr, n.y_ld, n.coef.f32(), q.y_ptr, q.y_ld, q.mask.u8(),
+          UNET_CALL(unet_bn_act_pool_bf16(n.zb.u16(), n.cop, n.y_ptr, n.y_ld, coef, q.y_ptr, q.y_ld, q.mask.u8(),
                                           batch, n.out_h, n.out_w, n.cop, act, stream_));
           q.pooled_by_parent = true;
           break;
         }
-        UNET_CALL(unet_bn_act_bf16(n.zb.u16(), n.cop, n.y_ptr, n.y_ld, n.coef.f32(), n.cop, out_pix, act, stream_));
+        UNET_CALL(unet_bn_act_bf16(n.zb.u16(), n.cop, n.y_ptr, n.y_ld, coef, n.cop, out_pix, act, stream_));
         break;
       }
       case MAX_POOL_LAYER: {
@@ -1344,6 +1360,7 @@ class Net {
   int step_count_ = 0;
   uint64_t seed_ = 0;
   bool params_dirty_ = true;
+  bool inf_coef_valid_ = false;  // Node::coef_inf match the current gamma/beta and running statistics
   DeviceBuffer pack_table_;  // per-layer arguments of the batched weight packing
   int pack_layers_ = 0, pack_boxes_ = 0;
   bool use_bf16_ = false;
