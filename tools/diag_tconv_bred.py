@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Runs the transposed-convolution data gradient with the fused batch-norm reduction several times on identical
+inputs (the shape of the last upsampling layer of the base-64 U-Net) and reports which outputs differ bit-wise
+between runs: dx (pixel, channel) positions and partial-sum rows.  None expected."""
+import os
+import sys
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from unet_amd import capi  # noqa: E402
+
+n, cp, cn, h, w = (int(v) for v in sys.argv[1:6]) if len(sys.argv) > 5 else (16, 128, 64, 128, 128)
+dev = "cuda:0"
+capi.unet_set_device(0)
+rng = np.random.default_rng(11)
+dzn = torch.from_numpy(rng.standard_normal((n, 2 * h, 2 * w, cn)).astype(np.float32)).to(dev).bfloat16()
+wflat = torch.from_numpy((rng.standard_normal(cp * cn * 4 + cn) * 0.1).astype(np.float32)).to(dev)
+wf = torch.zeros(4 * cn * cp, dtype=torch.bfloat16, device=dev)
+wb = torch.zeros(4 * cn * cp, dtype=torch.bfloat16, device=dev)
+capi.unet_pack_weights_bf16(wflat.data_ptr(), wf.data_ptr(), wb.data_ptr(), cp, cn, cp, cn, 2, None)
+zp = torch.from_numpy(rng.standard_normal((n, h, w, cp)).astype(np.float32)).to(dev).bfloat16()
+coef_h = np.stack([rng.random(cp) + 0.5, rng.standard_normal(cp) * 0.3, rng.standard_normal(cp) * 0.1,
+                   rng.random(cp) + 0.7], axis=1).astype(np.float32)
+coef = torch.from_numpy(coef_h.reshape(-1)).to(dev)
+tiles = capi.lib().unet_conv3x3_stat_tiles(h, w)
+outs = []
+for rep in range(6):
+    dx = torch.zeros((n, h, w, cp), dtype=torch.bfloat16, device=dev)
+    parts = torch.zeros((n * tiles, cp, 2), device=dev)
+    capi.unet_tconv2x2_dgrad_bnred_bf16(dzn.data_ptr(), cn, wb.data_ptr(), dx.data_ptr(), cp, zp.data_ptr(), cp,
+                                        coef.data_ptr(), parts.data_ptr(), n, h, w, cp, cn, None)
+    torch.cuda.synchronize()
+    outs.append((dx.view(torch.int16).cpu().numpy(), parts.cpu().numpy()))
+for rep in range(1, 6):
+    ddx = outs[rep][0] != outs[0][0]
+    dpt = outs[rep][1] != outs[0][1]
+    print(f"run {rep}: dx differs at {int(ddx.sum())} of {ddx.size}; partial sums differ at {int(dpt.sum())} of {dpt.size}")
+    if ddx.any():
+        idx = np.argwhere(ddx)
+        print("   dx first positions (n, y, x, c):", idx[:6].tolist(), " channels touched:", sorted(set(idx[:, 3].tolist()))[:16])
+    if dpt.any():
+        idx = np.argwhere(dpt)
+        rows = sorted(set(idx[:, 0].tolist()))
+        print("   rows:", rows[:10], "... (", len(rows), "rows ) channels:", sorted(set(idx[:, 1].tolist()))[:16],
+              " which:", sorted(set(idx[:, 2].tolist())),
+              " max rel diff", float(np.max(np.abs(outs[rep][1] - outs[0][1])[dpt] / (np.abs(outs[0][1])[dpt] + 1e-20))))

@@ -32,10 +32,20 @@ __device__ __forceinline__ bf16x8 tr_read_pair(const unsigned char *p0, const un
 // across rows are __shfl_xor (ds_bpermute_b32).  The gfx950 lane-swap instructions (v_permlane16/32_swap)
 // would make those VALU-only as well and measured 0.4 % faster on the whole step, but the sums then varied
 // from run to run (with the builtins and with inline asm plus wait states alike), so they are not used.
+// The operand passes through a wait (s_nop 1, tied to the register): whatever VALU instruction produced it then
+// retires at least two wait states before the DPP instruction reads it across lanes.  Without it one build of
+// the transposed-convolution data-gradient kernel (a packed fp32 multiply scheduled right before the rotation)
+// returned sums that differed between runs on identical inputs.
+__device__ __forceinline__ float dpp_operand(float v) {
+  asm volatile("s_nop 1" : "+v"(v));
+  return v;
+}
 __device__ __forceinline__ float lane_rot_sum8(float v) {  // + lane (i + 8) % 16 of the same 16-lane row
+  v = dpp_operand(v);
   return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xf, 0xf, true));
 }
 __device__ __forceinline__ float lane_rot_sum4(float v) {  // + lane (i + 4) % 16 of the same 16-lane row
+  v = dpp_operand(v);
   return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124, 0xf, 0xf, true));
 }
 template <int CH>

@@ -76,7 +76,7 @@ struct ConvArgs {
 // AFF: forward-only variant that folds inference-time batch norm + ReLU into the epilogue (a.affine); a
 // template parameter so that the training kernels carry none of it.
 template <int TAPS, int BN, bool BRED, int KC, int MMA = 0, bool AFF = false>
-__global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(256, (TAPS == 1 && BN == 64 && KC == 64) ? 3 : 2) void conv_mfma_kernel(const ConvArgs a) {
   static_assert(!(AFF && BRED), "the folded BN + ReLU epilogue is a forward variant");
   static_assert(MMA == 0 || (TAPS == 9 && KC == 32), "the 16x16x32 path is written for the 3x3 kernels");
   constexpr int PITCH = MMA ? 64 : KC * 2 + 16;  // bytes per LDS row of KC bf16 (MMA 0: + 16-byte pad)
