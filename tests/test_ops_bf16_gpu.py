@@ -612,3 +612,38 @@ def test_inference_bn_relu_folded_into_the_epilogue(G, capi, oracle, kind):
     assert_close_bf16(got, y_ref, what=f"{kind} + BN + ReLU folded")
     assert_close_bf16(got, from_nhwc(G, capi, y_plain, co), what=f"{kind}: folded vs unfused")
     assert np.all(y_fused.float().cpu().numpy()[..., co:] == 0), "padded channels must stay zero"
+
+
+@pytest.mark.parametrize("kind", ["conv", "tconv"])
+def test_fused_bn_reduction_is_bit_identical_between_runs(G, capi, kind):
+    """The data-gradient kernels with the fused batch-norm reduction, several runs on identical inputs at a size
+    that fills the device: dx and every per-tile sum must come out bit for bit the same (their cross-lane sums use
+    DPP row rotations, whose operand has to be two wait states old -- one build without that wait was not
+    deterministic)."""
+    n, cp, cn, h, w = 8, 128, 64, 64, 64
+    rng = np.random.default_rng(5)
+    k = 3 if kind == "conv" else 2
+    hz, wz = (h, w) if kind == "conv" else (2 * h, 2 * w)
+    dzn = torch.from_numpy(rng.standard_normal((n, hz, wz, cn)).astype(np.float32)).to(G.DEV).bfloat16()
+    wflat = (rng.standard_normal(cp * cn * k * k + cn) * 0.1).astype(np.float32)
+    _, wb = pack(G, capi, wflat, cp, cn, k)
+    zp = torch.from_numpy(rng.standard_normal((n, h, w, cp)).astype(np.float32)).to(G.DEV).bfloat16()
+    coef_h = np.stack([rng.random(cp) + 0.5, rng.standard_normal(cp) * 0.3, rng.standard_normal(cp) * 0.1,
+                       rng.random(cp) + 0.7], axis=1).astype(np.float32)
+    coef = G.dev(coef_h.reshape(-1))
+    tiles = capi.lib().unet_conv3x3_stat_tiles(h, w)
+    outs = []
+    for _ in range(5):
+        dx = torch.zeros((n, h, w, cp), dtype=torch.bfloat16, device=G.DEV)
+        parts = G.empty((n * tiles * cp * 2,))
+        if kind == "conv":
+            capi.unet_conv3x3_dgrad_bnred_bf16(G.p(dzn), cn, G.p(wb), G.p(dx), cp, G.p(zp), cp, G.p(coef), G.p(parts), 0,
+                                               n, h, w, cn, cp, None)
+        else:
+            capi.unet_tconv2x2_dgrad_bnred_bf16(G.p(dzn), cn, G.p(wb), G.p(dx), cp, G.p(zp), cp, G.p(coef), G.p(parts),
+                                                n, h, w, cp, cn, None)
+        torch.cuda.synchronize()
+        outs.append((dx.clone(), parts.clone()))
+    for dx, parts in outs[1:]:
+        assert torch.equal(dx, outs[0][0])
+        assert torch.equal(parts, outs[0][1])
