@@ -32,12 +32,13 @@ __device__ __forceinline__ bf16x8 tr_read_pair(const unsigned char *p0, const un
 // across rows are __shfl_xor (ds_bpermute_b32).  The gfx950 lane-swap instructions (v_permlane16/32_swap)
 // would make those VALU-only as well and measured 0.4 % faster on the whole step, but the sums then varied
 // from run to run (with the builtins and with inline asm plus wait states alike), so they are not used.
-// The operand passes through a wait (s_nop 1, tied to the register): whatever VALU instruction produced it then
-// retires at least two wait states before the DPP instruction reads it across lanes.  Without it one build of
-// the transposed-convolution data-gradient kernel (a packed fp32 multiply scheduled right before the rotation)
+// The operand passes through a wait (s_nop 4, tied to the register): whatever VALU instruction produced it then
+// retires at least five wait states before the DPP instruction reads it across lanes.  Two is the documented
+// distance from a VALU write to a DPP read; the margin is wider because without the wait one build of the
+// transposed-convolution data-gradient kernel -- a packed fp32 multiply scheduled right before the rotation --
 // returned sums that differed between runs on identical inputs.
 __device__ __forceinline__ float dpp_operand(float v) {
-  asm volatile("s_nop 1" : "+v"(v));
+  asm volatile("s_nop 4" : "+v"(v));
   return v;
 }
 __device__ __forceinline__ float lane_rot_sum8(float v) {  // + lane (i + 8) % 16 of the same 16-lane row
