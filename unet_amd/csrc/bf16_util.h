@@ -30,8 +30,8 @@ __device__ __forceinline__ bf16x8 tr_read_pair(const unsigned char *p0, const un
 // Sum over the lanes of a wavefront that share (lane % CH), CH a power of two in [4, 32]; every lane gets
 // the total.  The stages inside a 16-lane row are DPP row rotations (VALU, no LDS traffic); the two stages
 // across rows are __shfl_xor (ds_bpermute_b32).  The gfx950 lane-swap instructions (v_permlane16/32_swap)
-// would make those VALU-only as well and measured 0.4 % faster on the whole step, but the sums then varied
-// from run to run (with the builtins and with inline asm plus wait states alike), so they are not used.
+// make those VALU-only as well; without a wait on their operand the sums varied from run to run (see
+// dpp_operand below), with it they are exact but no faster on the whole step, so they are not used.
 // The operand passes through a wait (s_nop 4, tied to the register): whatever VALU instruction produced it then
 // retires at least five wait states before the DPP instruction reads it across lanes.  Two is the documented
 // distance from a VALU write to a DPP read; the margin is wider because without the wait one build of the
