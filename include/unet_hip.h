@@ -138,6 +138,17 @@ int unet_convolve_backward_f32(const float *grad_activations, const float *input
 int unet_batch_norm_train_f32(const float *inputs, float *activations, const float *weights,
                               float *BN_batch_stats, float *BN_running_stats, int num_channels,
                               int H, int W, int batch_size, unet_stream_t stream);
+/* unet_batch_norm_train_f32 for callers that cannot allocate device memory (code under HIP graph capture,
+ * tight serving loops, harnesses that forbid hipMalloc).  It has no counterpart in the reference.  Same
+ * arguments and results; the per-slice partial sums go to a fixed 1 MiB array inside the library's device
+ * image instead of the grow-only workspace, and the call performs no hipMalloc / hipFree.  Shapes whose
+ * partial sums do not fit (more than unet_batch_norm_train_noalloc_max_partials() (channel, slice) pairs;
+ * at most 512 slices per channel are ever used, so any C <= 256 fits) return UNET_ERR_INVALID.  All calls on
+ * one GPU share that GPU's array: calls that overlap on one GPU (different streams or threads) race. */
+int unet_batch_norm_train_noalloc_f32(const float *inputs, float *activations, const float *weights,
+                                      float *BN_batch_stats, float *BN_running_stats, int num_channels,
+                                      int H, int W, int batch_size, unet_stream_t stream);
+int unet_batch_norm_train_noalloc_max_partials(void);
 /* Replaces cudaBatchNormInference: y = gamma*(x-mean)/sqrt(var+1e-8)+beta with
  * the running statistics.  Extra argument batch_size (the reference handles
  * one image only). */

@@ -6,6 +6,8 @@
 // optimiser.  Convolution and transposed convolution live in conv_f32.hip.
 #include <math.h>
 
+#include <mutex>
+
 #include "common.h"
 
 #define BN_EPS 1e-8f
@@ -585,6 +587,24 @@ static dim3 bn_apply_grid(i64 HW, i64 planes) {
   return dim3(gx, gy);
 }
 
+// The three launches of the training forward; `partials` holds 2*C*S floats, every one of which the first
+// kernel overwrites.
+static int bn_train_launch(const float *inputs, float *activations, const float *weights, float *BN_batch_stats,
+                           float *BN_running_stats, int C, i64 HW, int N, int S, float *partials, unet_stream_t s) {
+  const i64 M = HW * N;
+  hipLaunchKernelGGL(bn_partial_kernel<0>, dim3(S, C), dim3(256), 0, as_stream(s), inputs,
+                     (const float *)nullptr, (const float *)nullptr, partials, C, HW, M, S);
+  UNET_LAUNCH_CHECK("bn_partial_kernel<0>");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)C), dim3(64), 0, as_stream(s), (const float *)partials,
+                     BN_batch_stats, BN_running_stats, C, S, (float)M);
+  UNET_LAUNCH_CHECK("bn_finalize_kernel");
+  hipLaunchKernelGGL(bn_apply_kernel<0>, bn_apply_grid(HW, (i64)N * C), dim3(256), 0, as_stream(s), inputs,
+                     (const float *)nullptr, activations, weights, (const float *)BN_batch_stats,
+                     (const float *)nullptr, C, HW, (i64)N * C, (float)M);
+  UNET_LAUNCH_CHECK("bn_apply_kernel<0>");
+  return UNET_OK;
+}
+
 int unet_batch_norm_train_f32(const float *inputs, float *activations, const float *weights,
                               float *BN_batch_stats, float *BN_running_stats, int C, int H, int W,
                               int N, unet_stream_t s) {
@@ -596,17 +616,55 @@ int unet_batch_norm_train_f32(const float *inputs, float *activations, const flo
   void *ws;
   rc = unet_workspace(&ws, sizeof(float) * 2 * (size_t)C * S, as_stream(s));
   if (rc) return rc;
-  hipLaunchKernelGGL(bn_partial_kernel<0>, dim3(S, C), dim3(256), 0, as_stream(s), inputs,
-                     (const float *)nullptr, (const float *)nullptr, (float *)ws, C, HW, M, S);
-  UNET_LAUNCH_CHECK("bn_partial_kernel<0>");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)C), dim3(64), 0, as_stream(s), (const float *)ws,
-                     BN_batch_stats, BN_running_stats, C, S, (float)M);
-  UNET_LAUNCH_CHECK("bn_finalize_kernel");
-  hipLaunchKernelGGL(bn_apply_kernel<0>, bn_apply_grid(HW, (i64)N * C), dim3(256), 0, as_stream(s), inputs,
-                     (const float *)nullptr, activations, weights, (const float *)BN_batch_stats,
-                     (const float *)nullptr, C, HW, (i64)N * C, (float)M);
-  UNET_LAUNCH_CHECK("bn_apply_kernel<0>");
+  return bn_train_launch(inputs, activations, weights, BN_batch_stats, BN_running_stats, C, HW, N, S, (float *)ws, s);
+}
+
+// ---- batch norm training forward for callers that must not allocate --------------------------------
+// The per-slice partial sums live in a fixed array in the library's device image instead of the grow-only
+// workspace.  Every GPU the library runs on holds its own copy of the array at its own address, looked up
+// once per device; host code only ever uses that looked-up address.
+#define UNET_BN_SCRATCH_FLOATS (256 * 1024) /* 1 MiB per GPU */
+static __device__ __align__(256) float g_bn_scratch[UNET_BN_SCRATCH_FLOATS];
+namespace {
+constexpr int kMaxDevices = 64;
+float *g_bn_scratch_ptr[kMaxDevices] = {};
+std::mutex g_bn_scratch_mu;
+}  // namespace
+
+static int bn_scratch_of_current_device(float **out) {
+  int dev = -1;
+  UNET_HIP_TRY(hipGetDevice(&dev));
+  UNET_REQUIRE(dev >= 0 && dev < kMaxDevices, "unet_batch_norm_train_noalloc_f32: device %d out of range", dev);
+  std::lock_guard<std::mutex> lk(g_bn_scratch_mu);
+  if (!g_bn_scratch_ptr[dev]) {
+    float *ptr = nullptr;
+    UNET_HIP_TRY(hipGetSymbolAddress((void **)&ptr, HIP_SYMBOL(g_bn_scratch)));
+    UNET_REQUIRE(ptr, "unet_batch_norm_train_noalloc_f32: the scratch array has no address on device %d", dev);
+    g_bn_scratch_ptr[dev] = ptr;
+  }
+  *out = g_bn_scratch_ptr[dev];
   return UNET_OK;
+}
+
+int unet_batch_norm_train_noalloc_max_partials(void) { return UNET_BN_SCRATCH_FLOATS / 2; }
+
+int unet_batch_norm_train_noalloc_f32(const float *inputs, float *activations, const float *weights,
+                                      float *BN_batch_stats, float *BN_running_stats, int C, int H, int W,
+                                      int N, unet_stream_t s) {
+  int rc = bn_check("unet_batch_norm_train_noalloc_f32", C, H, W, N);
+  if (rc) return rc;
+  UNET_REQUIRE(inputs && activations && weights && BN_batch_stats,
+               "unet_batch_norm_train_noalloc_f32: NULL pointer");
+  const i64 HW = (i64)H * W, M = HW * N;
+  const int S = bn_splits(M, C);
+  UNET_REQUIRE((i64)2 * C * S <= UNET_BN_SCRATCH_FLOATS,
+               "unet_batch_norm_train_noalloc_f32: %d channels x %d slices need %lld scratch floats, the fixed "
+               "scratch holds %d; use unet_batch_norm_train_f32",
+               C, S, (long long)2 * C * S, UNET_BN_SCRATCH_FLOATS);
+  float *scratch = nullptr;
+  rc = bn_scratch_of_current_device(&scratch);
+  if (rc) return rc;
+  return bn_train_launch(inputs, activations, weights, BN_batch_stats, BN_running_stats, C, HW, N, S, scratch, s);
 }
 
 int unet_batch_norm_inference_f32(const float *inputs, float *activations, const float *weights,
