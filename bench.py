@@ -53,6 +53,39 @@ def conv_flops(graph, batch):
     return fwd * batch, total * batch
 
 
+def family_flops(graph, batch):
+    """Algorithmic FLOPs per step of each timed MFMA kernel family, from the layer table alone
+    (logical channel counts: 3 input channels on the first layer, not the 32 the kernel pads to).
+    The one-output-channel head goes to its own family."""
+    fam = {"conv3x3_fwd_bf16": 0.0, "conv3x3_dgrad_bf16": 0.0, "conv3x3_wgrad_bf16": 0.0, "tconv2x2_bf16": 0.0,
+           "tconv2x2_wgrad_bf16": 0.0, "conv3x3_head_bf16": 0.0}
+    for kind, s, parents, _ in graph:
+        if kind == "conv":
+            f = 2.0 * s[0] * s[1] * s[3] * s[2] * s[4] * s[4] * batch
+            if s[3] == 1:
+                fam["conv3x3_head_bf16"] += f * (3 if parents else 2)
+                continue
+            fam["conv3x3_fwd_bf16"] += f
+            fam["conv3x3_wgrad_bf16"] += f
+            if parents:
+                fam["conv3x3_dgrad_bf16"] += f
+        elif kind == "up":
+            f = 2.0 * (s[0] * s[4]) * (s[1] * s[4]) * s[3] * s[2] * batch
+            fam["tconv2x2_bf16"] += 2 * f      # forward and data gradient run the same kernel
+            fam["tconv2x2_wgrad_bf16"] += f
+    return fam
+
+
+def source_hash(*names):
+    """Short hash of kernel source files: ties committed counter data to the build it was measured on."""
+    import hashlib
+    h = hashlib.sha1()
+    for n in names:
+        with open(os.path.join(ROOT, "unet_amd", "csrc", n), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:12]
+
+
 def cpu_baseline_port(seconds_budget=30.0):
     """Times the CPU oracle (single thread, plain C) on a bounded sample of the
     workload: three images through the 64->64 3x3 convolution at 256x256 (forward +
@@ -176,6 +209,15 @@ def main():
                     kind=k, launches=n.value, ms=ms.value, flops=fl.value, bytes=by.value)
         return fams
 
+    def algorithmic(fams, steps):
+        """The library's timers attribute FLOPs from the padded channel counts its kernels see; replace
+        them by the algorithmic figure of the layer table for the families the table covers."""
+        alg = family_flops(graph, args.batch)
+        for name, f in fams.items():
+            if name in alg and dtype == "bf16":
+                f["flops"] = alg[name] * steps
+        return fams
+
     def group_kernels(fams):
         kernels = {}
         for fam, f in fams.items():
@@ -199,7 +241,7 @@ def main():
         for _ in range(probe_steps):
             trainer.train_step(images.data_ptr(), masks.data_ptr(), args.batch, lr)
         sync()
-        probe = read_families()
+        probe = algorithmic(read_families(), probe_steps)
         dominant_mask = max(group_kernels(probe).values(), key=lambda k: k["ms"])["mask"]
         # Timed region: events only around the launches of the dominant kernel.
         capi.unet_prof_enable_kinds(dominant_mask)
@@ -216,7 +258,7 @@ def main():
 
     families = {}
     if probe_steps:
-        families = read_families()   # the dominant kernel's families, timed inside the timed region
+        families = algorithmic(read_families(), args.steps)   # the dominant kernel's families, timed inside the timed region
         capi.unet_prof_enable(0)
 
     loss = None
@@ -236,7 +278,7 @@ def main():
     value = args.batch * world * args.steps / elapsed
     fwd_flops, step_flops = conv_flops(graph, args.batch)
     out = {
-        "metric": "U-Net train images/s (fwd+bwd, 256x256, bf16)",
+        "metric": f"U-Net train images/s (fwd+bwd, {H}x{W}, {dtype})",
         "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
@@ -271,11 +313,14 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic_per_kernel.json")
         default_workload = (args.graph == "unet4_base64" and args.batch == 16 and args.size == 256 and
                             args.base == 64 and dtype == "bf16")
-        if default_workload and os.path.exists(tpath):
+        traffic = json.load(open(tpath)) if default_workload and os.path.exists(tpath) else {}
+        # the counters describe one build of the kernels: a file collected on other sources is not reported
+        if traffic.get("_source_hash") == source_hash("conv_bf16.hip", "wgrad_bf16.hip", "bf16_util.h"):
             # "conv_mfma_kernel<9,64>" covers the template instances "conv_mfma_kernel<9, 64, false|true>"
             # (without / with the fused batch-norm-backward reduction): launch-weighted mean
             want = name.replace(",", ", ")[:-1]
-            recs = [rec for kname, rec in json.load(open(tpath)).items() if want + ">" in kname or want + "," in kname]
+            recs = [rec for kname, rec in traffic.items()
+                    if isinstance(rec, dict) and (want + ">" in kname or want + "," in kname)]
             if recs:
                 n = sum(r["launches"] for r in recs)
                 out["roofline"]["traffic"] = round(sum(r["traffic_bytes_per_launch"] * r["launches"] for r in recs) / n)

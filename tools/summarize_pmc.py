@@ -10,6 +10,7 @@ and writes 12 bytes per parameter)."""
 import collections
 import csv
 import json
+import os
 import sys
 
 
@@ -32,8 +33,12 @@ def main():
         wr = wv * 1024 / wn if wn else 0.0
         out[k] = {"launches": n, "read_bytes_per_launch": round(rd), "write_bytes_per_launch": round(wr),
                   "traffic_bytes_per_launch": round(rd + wr)}
-    json.dump(dict(sorted(out.items(), key=lambda kv: -kv[1]["traffic_bytes_per_launch"] * kv[1]["launches"])),
-              open(sys.argv[3], "w"), indent=1)
+    out = dict(sorted(out.items(), key=lambda kv: -kv[1]["traffic_bytes_per_launch"] * kv[1]["launches"]))
+    # the kernel sources these counters were collected on (bench.py reports the traffic only for this build)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    out["_source_hash"] = bench.source_hash("conv_bf16.hip", "wgrad_bf16.hip", "bf16_util.h")
+    json.dump(out, open(sys.argv[3], "w"), indent=1)
 
 
 if __name__ == "__main__":
