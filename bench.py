@@ -269,6 +269,7 @@ def main():
         lv = lv.cpu().numpy().reshape(-1, 3)
         loss = float(1.0 - np.mean(2 * lv[:, 0] / (lv[:, 1] + lv[:, 2] + 1e-5)))
 
+    trainer.close()
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()

@@ -320,6 +320,36 @@ int unet_u8_to_f32(const uint8_t *in, float *out, int64_t num_elements, float sc
 /* x *= alpha (gradient averaging across data-parallel ranks). */
 int unet_scale_f32(float *x, float alpha, int64_t num_elements, unet_stream_t stream);
 
+/* ---- data-parallel collectives (RCCL over xGMI) ---------------------------------
+ * The reference trains on one device (no collective anywhere in src/); these entry points are what
+ * batch-sharded training adds: one process per GPU, one communicator rank per process, the gradient mean
+ * taken bucket by bucket on the communicator's own stream while backward continues.
+ *   unet_comm_get_unique_id   rank 0 fills unet_comm_unique_id_bytes() bytes of host memory, which the caller
+ *                             hands to every rank over any host channel (a file, MPI, torch.distributed, ...)
+ *   unet_comm_init_rank       collective over all ranks; the communicator belongs to the current device
+ *   unet_allreduce_begin      data[0:count] = mean over ranks, in place, enqueued on the communication stream
+ *                             after `ready` (an event recorded on the compute stream once the bucket's last
+ *                             gradient was written; NULL = no wait); returns at once
+ *   unet_allreduce_wait       makes `stream` wait for every unet_allreduce_begin issued so far
+ *   unet_allreduce_sum_f32, unet_broadcast_f32   in place, on `stream` itself
+ *   unet_bn_set_sync          comm != NULL: the batch-norm training entry points (fp32 and bf16, forward and
+ *                             backward) add their per-channel sums over the communicator's ranks, so that
+ *                             every rank normalises with the statistics of the global batch and the result
+ *                             equals single-GPU training on that batch (every rank must hold the same number
+ *                             of elements; gamma/beta gradients come out divided by the number of ranks so
+ *                             that the gradient mean is the global gradient).  NULL: per-rank statistics. */
+typedef void *unet_comm_t;
+int unet_comm_unique_id_bytes(void);
+int unet_comm_get_unique_id(void *id_host);
+int unet_comm_init_rank(unet_comm_t *comm, const void *id_host, int world_size, int rank);
+int unet_comm_destroy(unet_comm_t comm);
+int unet_comm_size(unet_comm_t comm, int *world_size, int *rank);
+int unet_allreduce_begin(unet_comm_t comm, float *data, int64_t count, unet_event_t ready);
+int unet_allreduce_wait(unet_comm_t comm, unet_stream_t stream);
+int unet_allreduce_sum_f32(unet_comm_t comm, float *data, int64_t count, unet_stream_t stream);
+int unet_broadcast_f32(unet_comm_t comm, float *data, int64_t count, int root, unet_stream_t stream);
+int unet_bn_set_sync(unet_comm_t comm);
+
 /* ==== bf16 / NHWC fast path =================================================
  * The training hot path of the network engine.  Activations are NHWC bf16
  * (uint16_t storage) with a pixel stride `ld` in elements, so a tensor may be

@@ -24,6 +24,7 @@ _SCALARS = {
     "size_t": ctypes.c_size_t,
     "unet_stream_t": ctypes.c_void_p,
     "unet_event_t": ctypes.c_void_p,
+    "unet_comm_t": ctypes.c_void_p,
 }
 
 

@@ -39,6 +39,11 @@ int unet_set_error(int code, const char *fmt, ...);
 int unet_workspace(void **ptr, size_t bytes, hipStream_t stream);
 void unet_workspace_release_all();
 
+// Batch-norm statistics shared across data-parallel ranks (comm.hip): whether a communicator was selected with
+// unet_bn_set_sync, and the in-place cross-rank sum of `count` doubles on stream `s` (*world = number of ranks).
+bool unet_bn_sync_on();
+int unet_bn_sync_sum_f64(double *data, i64 count, int *world, hipStream_t s);
+
 static inline hipStream_t as_stream(unet_stream_t s) { return (hipStream_t)s; }
 
 // ---- per-kernel timing (unet_prof_* in the C ABI) ---------------------------

@@ -48,26 +48,29 @@ struct ChanBwd {
 // channel: threads stride over the P partials with eight independent loads in flight, accumulate
 // in double, combine with xor shuffles and a fixed-order sum over the four wavefronts
 // (reproducible).  Every thread of the workgroup returns the totals.
-__device__ __forceinline__ void block_sum_partials(const float *__restrict__ partials, int P, int CoP, int c,
+template <typename T>  // float: per-tile / per-block partials; double: sums already combined across ranks
+__device__ __forceinline__ void block_sum_partials(const T *__restrict__ partials, int P, int CoP, int c,
                                                     double &s, double &q) {
   __shared__ double red[2][4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   double a = 0, b = 0;
   int p = tid;
   for (; p + 7 * 256 < P; p += 8 * 256) {
-    float2 v[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float2 *>(partials + ((i64)(p + u * 256) * CoP + c) * 2);
+    T v[8][2];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-      a += v[u].x;
-      b += v[u].y;
+      v[u][0] = partials[((i64)(p + u * 256) * CoP + c) * 2];
+      v[u][1] = partials[((i64)(p + u * 256) * CoP + c) * 2 + 1];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      a += v[u][0];
+      b += v[u][1];
     }
   }
   for (; p < P; p += 256) {
-    const float2 v = *reinterpret_cast<const float2 *>(partials + ((i64)p * CoP + c) * 2);
-    a += v.x;
-    b += v.y;
+    a += partials[((i64)p * CoP + c) * 2];
+    b += partials[((i64)p * CoP + c) * 2 + 1];
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
@@ -84,7 +87,8 @@ __device__ __forceinline__ void block_sum_partials(const float *__restrict__ par
 }
 
 // partials [P][CoP][2] (sum, sum of squares) -> batch_stats, running stats, ChanFwd
-__global__ __launch_bounds__(256) void bn_finalize_fwd_kernel(const float *__restrict__ partials, int P, int C,
+template <typename T>
+__global__ __launch_bounds__(256) void bn_finalize_fwd_kernel(const T *__restrict__ partials, int P, int C,
                                                               int CoP, float M, const float *__restrict__ gb,
                                                               float *__restrict__ batch_stats,
                                                               float *__restrict__ running,
@@ -253,19 +257,21 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const bf16_t *__rest
   }
 }
 
-// sums partials; writes grad_gb[2c] = dgamma, [2c+1] = dbeta and the ChanBwd record
-__global__ __launch_bounds__(256) void bn_finalize_bwd_kernel(const float *__restrict__ partials, int P, int C,
+// sums partials; writes grad_gb[2c] = dgamma, [2c+1] = dbeta (times grad_scale) and the ChanBwd record
+template <typename T>
+__global__ __launch_bounds__(256) void bn_finalize_bwd_kernel(const T *__restrict__ partials, int P, int C,
                                                               int CoP, float M, const float *__restrict__ gb,
                                                               const ChanFwd *__restrict__ cf,
-                                                              float *__restrict__ grad_gb, ChanBwd *__restrict__ out) {
+                                                              float *__restrict__ grad_gb, ChanBwd *__restrict__ out,
+                                                              float grad_scale) {
   const int c = blockIdx.x;  // one workgroup per channel
   ChanBwd r{0.f, 0.f, 0.f, 0.f};
   if (c < C) {
     double dg, db;
     block_sum_partials(partials, P, CoP, c, dg, db);
     if (threadIdx.x == 0) {
-      grad_gb[2 * c] = (float)dg;
-      grad_gb[2 * c + 1] = (float)db;
+      grad_gb[2 * c] = (float)dg * grad_scale;
+      grad_gb[2 * c + 1] = (float)db * grad_scale;
     }
     r.c0 = gb[2 * c] * cf[c].invb;
     r.k1 = (float)(db / M);
@@ -670,6 +676,65 @@ __global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const bf16_t *__restr
   }
 }
 
+// sums[c] = sum_p partial[p][c] in double, c < ncols (the statistics a rank contributes to the
+// cross-rank sum when batch-norm statistics are synchronised)
+__global__ __launch_bounds__(256) void column_sum_f64_kernel(const float *__restrict__ partial, int P, int ncols,
+                                                             double *__restrict__ out) {
+  __shared__ double red[4];
+  const int c = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  double s = 0;
+  for (int p = tid; p < P; p += 256) s += partial[(i64)p * ncols + c];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (lane == 0) red[wave] = s;
+  __syncthreads();
+  if (tid == 0) out[c] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// The two finalize steps.  With statistics synchronised across data-parallel ranks (unet_bn_set_sync) each
+// rank first adds up its own partials, the [CoP][2] sums are added across ranks in double, and the finalize
+// kernel then sees one row of global sums and the global element count; gamma/beta gradients are divided by
+// the number of ranks so that the mean over ranks taken by the gradient all-reduce is the global gradient.
+// `sync_ws` holds 2*CoP doubles.  Synchronised statistics require the same element count on every rank.
+int launch_finalize_fwd(const float *partials, int P, int C, int CoP, i64 count, const float *gb, float *batch_stats,
+                        float *running, ChanFwd *out, double *sync_ws, hipStream_t s) {
+  if (!unet_bn_sync_on()) {
+    hipLaunchKernelGGL(bn_finalize_fwd_kernel<float>, dim3(CoP), dim3(256), 0, s, partials, P, C, CoP, (float)count, gb,
+                       batch_stats, running, out);
+    UNET_LAUNCH_CHECK("bn_finalize_fwd_kernel");
+    return UNET_OK;
+  }
+  hipLaunchKernelGGL(column_sum_f64_kernel, dim3(2 * CoP), dim3(256), 0, s, partials, P, 2 * CoP, sync_ws);
+  UNET_LAUNCH_CHECK("column_sum_f64_kernel");
+  int world = 1;
+  int rc = unet_bn_sync_sum_f64(sync_ws, 2 * (i64)CoP, &world, s);
+  if (rc) return rc;
+  hipLaunchKernelGGL(bn_finalize_fwd_kernel<double>, dim3(CoP), dim3(256), 0, s, (const double *)sync_ws, 1, C, CoP,
+                     (float)(count * world), gb, batch_stats, running, out);
+  UNET_LAUNCH_CHECK("bn_finalize_fwd_kernel");
+  return UNET_OK;
+}
+
+int launch_finalize_bwd(const float *partials, int P, int C, int CoP, i64 count, const float *gb, const ChanFwd *cf,
+                        float *grad_gb, ChanBwd *out, double *sync_ws, hipStream_t s) {
+  if (!unet_bn_sync_on()) {
+    hipLaunchKernelGGL(bn_finalize_bwd_kernel<float>, dim3(CoP), dim3(256), 0, s, partials, P, C, CoP, (float)count, gb,
+                       cf, grad_gb, out, 1.0f);
+    UNET_LAUNCH_CHECK("bn_finalize_bwd_kernel");
+    return UNET_OK;
+  }
+  hipLaunchKernelGGL(column_sum_f64_kernel, dim3(2 * CoP), dim3(256), 0, s, partials, P, 2 * CoP, sync_ws);
+  UNET_LAUNCH_CHECK("column_sum_f64_kernel");
+  int world = 1;
+  int rc = unet_bn_sync_sum_f64(sync_ws, 2 * (i64)CoP, &world, s);
+  if (rc) return rc;
+  hipLaunchKernelGGL(bn_finalize_bwd_kernel<double>, dim3(CoP), dim3(256), 0, s, (const double *)sync_ws, 1, C, CoP,
+                     (float)(count * world), gb, cf, grad_gb, out, 1.0f / (float)world);
+  UNET_LAUNCH_CHECK("bn_finalize_bwd_kernel");
+  return UNET_OK;
+}
+
 struct RedPlan {
   int CG, PL, blocks;
   i64 ppb;
@@ -704,11 +769,15 @@ int unet_bn_finalize_bf16(const float *stat_partials, int num_partials, int C, i
                           unet_stream_t s) {
   UNET_REQUIRE(stat_partials && gamma_beta && batch_stats && coef, "unet_bn_finalize_bf16: NULL pointer");
   UNET_REQUIRE(num_partials > 0 && C > 0 && CoP >= C && count > 0, "unet_bn_finalize_bf16: bad sizes");
-  hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(CoP), dim3(256), 0, as_stream(s), stat_partials,
-                     num_partials, C, CoP, (float)count, gamma_beta, batch_stats, running_stats,
-                     reinterpret_cast<ChanFwd *>(coef));
-  UNET_LAUNCH_CHECK("bn_finalize_fwd_kernel");
-  return UNET_OK;
+  double *sync_ws = nullptr;
+  if (unet_bn_sync_on()) {
+    void *ws;
+    int rc = unet_workspace(&ws, sizeof(double) * 2 * (size_t)CoP, as_stream(s));
+    if (rc) return rc;
+    sync_ws = (double *)ws;
+  }
+  return launch_finalize_fwd(stat_partials, num_partials, C, CoP, count, gamma_beta, batch_stats, running_stats,
+                             reinterpret_cast<ChanFwd *>(coef), sync_ws, as_stream(s));
 }
 
 int unet_bn_inference_coef_bf16(const float *gamma_beta, const float *running_stats, int C, int CoP, float *coef,
@@ -753,12 +822,14 @@ int unet_bn_act_backward_bf16(const uint16_t *dy1, int ld1, const uint16_t *dy2,
                    act >= 0 && act <= 2,
                "unet_bn_act_backward_bf16: bad argument (CoP must be a multiple of 8, at most 2048)");
   const RedPlan pl = plan_reduce(CoP, pixels);
-  // workspace: partials [blocks][CoP][2] | ChanBwd [CoP] | bias partials [blocks][CoP]
-  const size_t n_part = (size_t)pl.blocks * CoP * 2, n_cb = (size_t)CoP * 4, n_bias = (size_t)pl.blocks * CoP;
+  // workspace: cross-rank sums [CoP][2] double | partials [blocks][CoP][2] | ChanBwd [CoP] | bias partials [blocks][CoP]
+  const size_t n_sync = (size_t)CoP * 4, n_part = (size_t)pl.blocks * CoP * 2, n_cb = (size_t)CoP * 4,
+               n_bias = (size_t)pl.blocks * CoP;
   void *ws;
-  rc = unet_workspace(&ws, sizeof(float) * (n_part + n_cb + n_bias), as_stream(s));
+  rc = unet_workspace(&ws, sizeof(float) * (n_sync + n_part + n_cb + n_bias), as_stream(s));
   if (rc) return rc;
-  float *partial = (float *)ws, *cbf = partial + n_part, *bias_part = cbf + n_cb;
+  double *sync_ws = (double *)ws;
+  float *partial = (float *)ws + n_sync, *cbf = partial + n_part, *bias_part = cbf + n_cb;
   const ChanFwd *cf = reinterpret_cast<const ChanFwd *>(coef);
   ChanBwd *cb = reinterpret_cast<ChanBwd *>(cbf);
   const size_t lds1 = sizeof(float) * (size_t)pl.PL * pl.CG * 16, lds2 = sizeof(float) * (size_t)pl.PL * pl.CG * 8;
@@ -771,9 +842,9 @@ int unet_bn_act_backward_bf16(const uint16_t *dy1, int ld1, const uint16_t *dy2,
                          dy2, ld2, z, z_ld, cf, pl.CG, pl.PL, (i64)pixels, pl.ppb, partial, CoP);                   \
     }                                                                                                               \
     UNET_LAUNCH_CHECK("bn_bwd_reduce_kernel");                                                                      \
-    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(CoP), dim3(256), 0, as_stream(s),                    \
-                       (const float *)partial, pl.blocks, C, CoP, (float)pixels, gamma_beta, cf, grad_gb, cb);      \
-    UNET_LAUNCH_CHECK("bn_finalize_bwd_kernel");                                                                    \
+    rc = launch_finalize_bwd(partial, pl.blocks, C, CoP, (i64)pixels, gamma_beta, cf, grad_gb, cb, sync_ws,        \
+                             as_stream(s));                                                                         \
+    if (rc) return rc;                                                                                              \
     {                                                                                                               \
       ProfScope prof(PROF_BN_BWD_APPLY_BF16, 0, 2.0 * elems * (dy2 ? 4.0 : 3.0), as_stream(s));                     \
       if (grad_bias)                                                                                               \
@@ -815,12 +886,14 @@ int unet_bn_act_backward_pooled_bf16(const uint16_t *dy, int dy_ld, const uint16
                "(at most 2048)");
   const i64 windows = (i64)N * (H / 2) * (W / 2), pixels = 4 * windows;
   const RedPlan pl = plan_reduce(CoP, windows);
-  // workspace: partials [blocks][CoP][2] | ChanBwd [CoP] | bias partials [blocks][CoP]
-  const size_t n_part = (size_t)pl.blocks * CoP * 2, n_cb = (size_t)CoP * 4, n_bias = (size_t)pl.blocks * CoP;
+  // workspace: cross-rank sums [CoP][2] double | partials [blocks][CoP][2] | ChanBwd [CoP] | bias partials [blocks][CoP]
+  const size_t n_sync = (size_t)CoP * 4, n_part = (size_t)pl.blocks * CoP * 2, n_cb = (size_t)CoP * 4,
+               n_bias = (size_t)pl.blocks * CoP;
   void *ws;
-  rc = unet_workspace(&ws, sizeof(float) * (n_part + n_cb + n_bias), as_stream(s));
+  rc = unet_workspace(&ws, sizeof(float) * (n_sync + n_part + n_cb + n_bias), as_stream(s));
   if (rc) return rc;
-  float *partial = (float *)ws, *cbf = partial + n_part, *bias_part = cbf + n_cb;
+  double *sync_ws = (double *)ws;
+  float *partial = (float *)ws + n_sync, *cbf = partial + n_part, *bias_part = cbf + n_cb;
   const ChanFwd *cf = reinterpret_cast<const ChanFwd *>(coef);
   ChanBwd *cb = reinterpret_cast<ChanBwd *>(cbf);
   const bf16_t *d1 = reinterpret_cast<const bf16_t *>(dy);
@@ -837,9 +910,9 @@ int unet_bn_act_backward_pooled_bf16(const uint16_t *dy, int dy_ld, const uint16
                          dy_ld, ps, zz, z_ld, cf, pl.CG, pl.PL, windows, pl.ppb, partial, CoP);                     \
     }                                                                                                               \
     UNET_LAUNCH_CHECK("bn_bwd_reduce_pool_kernel");                                                                 \
-    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(CoP), dim3(256), 0, as_stream(s), (const float *)partial,       \
-                       pl.blocks, C, CoP, (float)pixels, gamma_beta, cf, grad_gb, cb);                              \
-    UNET_LAUNCH_CHECK("bn_finalize_bwd_kernel");                                                                    \
+    rc = launch_finalize_bwd(partial, pl.blocks, C, CoP, pixels, gamma_beta, cf, grad_gb, cb, sync_ws,              \
+                             as_stream(s));                                                                         \
+    if (rc) return rc;                                                                                              \
     {                                                                                                               \
       ProfScope prof(PROF_BN_BWD_APPLY_BF16, 0, elems * (4.0 + grads), as_stream(s));                               \
       if (grad_bias)                                                                                                \
@@ -878,17 +951,17 @@ int unet_bn_act_backward_from_partials_bf16(const uint16_t *dy, int dy_ld, const
                    CoP % 8 == 0 && CoP <= 2048 && pixels > 0,
                "unet_bn_act_backward_from_partials_bf16: bad argument (CoP must be a multiple of 8, at most 2048)");
   const RedPlan pl = plan_reduce(CoP, pixels);
-  // workspace: ChanBwd [CoP] | bias partials [blocks][CoP]
-  const size_t n_cb = (size_t)CoP * 4, n_bias = (size_t)pl.blocks * CoP;
+  // workspace: cross-rank sums [CoP][2] double | ChanBwd [CoP] | bias partials [blocks][CoP]
+  const size_t n_sync = (size_t)CoP * 4, n_cb = (size_t)CoP * 4, n_bias = (size_t)pl.blocks * CoP;
   void *ws;
-  rc = unet_workspace(&ws, sizeof(float) * (n_cb + n_bias), as_stream(s));
+  rc = unet_workspace(&ws, sizeof(float) * (n_sync + n_cb + n_bias), as_stream(s));
   if (rc) return rc;
-  float *cbf = (float *)ws, *bias_part = cbf + n_cb;
+  float *cbf = (float *)ws + n_sync, *bias_part = cbf + n_cb;
   const ChanFwd *cf = reinterpret_cast<const ChanFwd *>(coef);
   ChanBwd *cb = reinterpret_cast<ChanBwd *>(cbf);
-  hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(CoP), dim3(256), 0, as_stream(s), red_partials,
-                     num_partials, C, CoP, (float)pixels, gamma_beta, cf, grad_gb, cb);
-  UNET_LAUNCH_CHECK("bn_finalize_bwd_kernel");
+  rc = launch_finalize_bwd(red_partials, num_partials, C, CoP, (i64)pixels, gamma_beta, cf, grad_gb, cb, (double *)ws,
+                           as_stream(s));
+  if (rc) return rc;
   {
     ProfScope prof(PROF_BN_BWD_APPLY_BF16, 0, 2.0 * (double)pixels * CoP * 3.0, as_stream(s));
     if (grad_bias)

@@ -158,7 +158,7 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float *__restrict
                                                          const float *__restrict__ dy,
                                                          const float *__restrict__ stats,
                                                          float *__restrict__ partial, int C, i64 HW,
-                                                         i64 M, int S) {
+                                                         i64 M, int S, float Mstat) {
   __shared__ float red[2 * 4];
   const int c = blockIdx.y, s = blockIdx.x;
   const i64 chunk = (M + S - 1) / S;
@@ -166,8 +166,8 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float *__restrict
   const i64 j1 = (j0 + chunk < M) ? j0 + chunk : M;
   float mean = 0.f, inv = 0.f;
   if (MODE == 1) {
-    mean = stats[2 * c] / (float)M;
-    float var = stats[2 * c + 1] / (float)M - mean * mean;
+    mean = stats[2 * c] / Mstat;  // Mstat: the element count the statistics were taken over (all ranks when synchronised)
+    float var = stats[2 * c + 1] / Mstat - mean * mean;
     var = var < 0.f ? 0.f : var;
     inv = 1.0f / sqrtf(var + BN_EPS);
   }
@@ -215,6 +215,42 @@ __global__ __launch_bounds__(64) void bn_finalize_kernel(const float *__restrict
     b += __shfl_xor(b, o, 64);
   }
   if (lane != 0) return;
+  out2[2 * c] = (float)a;
+  out2[2 * c + 1] = (float)b;
+  if (running) {
+    const float mean = (float)(a / M);
+    float var = (float)(b / M - (a / M) * (a / M));
+    var = var < 0.f ? 0.f : var;
+    running[2 * c] = running[2 * c] * BN_MOMENTUM + (1.0f - BN_MOMENTUM) * mean;
+    running[2 * c + 1] = running[2 * c + 1] * BN_MOMENTUM + (1.0f - BN_MOMENTUM) * var;
+  }
+}
+
+// Statistics synchronised across data-parallel ranks: the per-channel sums leave this rank as doubles
+// (sums[2c], sums[2c+1]), are added across ranks, and bn_publish_kernel then does what the tail of
+// bn_finalize_kernel does, with the global element count M.
+__global__ __launch_bounds__(64) void bn_finalize_f64_kernel(const float *__restrict__ partial, double *__restrict__ sums,
+                                                             int C, int S) {
+  const int c = blockIdx.x, lane = threadIdx.x;
+  double a = 0, b = 0;
+  for (int s = lane; s < S; s += 64) {
+    a += partial[((i64)c * S + s) * 2];
+    b += partial[((i64)c * S + s) * 2 + 1];
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    a += __shfl_xor(a, o, 64);
+    b += __shfl_xor(b, o, 64);
+  }
+  if (lane != 0) return;
+  sums[2 * c] = a;
+  sums[2 * c + 1] = b;
+}
+__global__ __launch_bounds__(64) void bn_publish_kernel(const double *__restrict__ sums, float *__restrict__ out2,
+                                                        float *__restrict__ running, int C, float M) {
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  if (c >= C) return;
+  const double a = sums[2 * c], b = sums[2 * c + 1];
   out2[2 * c] = (float)a;
   out2[2 * c + 1] = (float)b;
   if (running) {
@@ -587,20 +623,36 @@ static dim3 bn_apply_grid(i64 HW, i64 planes) {
   return dim3(gx, gy);
 }
 
-// The three launches of the training forward; `partials` holds 2*C*S floats, every one of which the first
-// kernel overwrites.
+// The launches of the training forward; `partials` holds 2*C*S floats, every one of which the first kernel
+// overwrites.  `sync_sums` (2*C doubles) is needed when the statistics are synchronised across ranks
+// (unet_bn_set_sync): the channel sums are then added over all ranks and M counts all ranks' elements.
 static int bn_train_launch(const float *inputs, float *activations, const float *weights, float *BN_batch_stats,
-                           float *BN_running_stats, int C, i64 HW, int N, int S, float *partials, unet_stream_t s) {
+                           float *BN_running_stats, int C, i64 HW, int N, int S, float *partials, double *sync_sums,
+                           unet_stream_t s) {
   const i64 M = HW * N;
+  float Mg = (float)M;
   hipLaunchKernelGGL(bn_partial_kernel<0>, dim3(S, C), dim3(256), 0, as_stream(s), inputs,
-                     (const float *)nullptr, (const float *)nullptr, partials, C, HW, M, S);
+                     (const float *)nullptr, (const float *)nullptr, partials, C, HW, M, S, Mg);
   UNET_LAUNCH_CHECK("bn_partial_kernel<0>");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)C), dim3(64), 0, as_stream(s), (const float *)partials,
-                     BN_batch_stats, BN_running_stats, C, S, (float)M);
-  UNET_LAUNCH_CHECK("bn_finalize_kernel");
+  if (sync_sums) {
+    hipLaunchKernelGGL(bn_finalize_f64_kernel, dim3((unsigned)C), dim3(64), 0, as_stream(s), (const float *)partials,
+                       sync_sums, C, S);
+    UNET_LAUNCH_CHECK("bn_finalize_f64_kernel");
+    int world = 1;
+    int rc = unet_bn_sync_sum_f64(sync_sums, 2 * (i64)C, &world, as_stream(s));
+    if (rc) return rc;
+    Mg = (float)(M * world);
+    hipLaunchKernelGGL(bn_publish_kernel, dim3(cdiv_u(C, 64)), dim3(64), 0, as_stream(s), (const double *)sync_sums,
+                       BN_batch_stats, BN_running_stats, C, Mg);
+    UNET_LAUNCH_CHECK("bn_publish_kernel");
+  } else {
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)C), dim3(64), 0, as_stream(s), (const float *)partials,
+                       BN_batch_stats, BN_running_stats, C, S, Mg);
+    UNET_LAUNCH_CHECK("bn_finalize_kernel");
+  }
   hipLaunchKernelGGL(bn_apply_kernel<0>, bn_apply_grid(HW, (i64)N * C), dim3(256), 0, as_stream(s), inputs,
                      (const float *)nullptr, activations, weights, (const float *)BN_batch_stats,
-                     (const float *)nullptr, C, HW, (i64)N * C, (float)M);
+                     (const float *)nullptr, C, HW, (i64)N * C, Mg);
   UNET_LAUNCH_CHECK("bn_apply_kernel<0>");
   return UNET_OK;
 }
@@ -613,10 +665,13 @@ int unet_batch_norm_train_f32(const float *inputs, float *activations, const flo
   UNET_REQUIRE(inputs && activations && weights && BN_batch_stats, "unet_batch_norm_train_f32: NULL pointer");
   const i64 HW = (i64)H * W, M = HW * N;
   const int S = bn_splits(M, C);
+  // workspace: cross-rank sums [2C] double (synchronised statistics only) | partials [C][S][2]
+  const size_t n_sync = unet_bn_sync_on() ? 4 * (size_t)C : 0;
   void *ws;
-  rc = unet_workspace(&ws, sizeof(float) * 2 * (size_t)C * S, as_stream(s));
+  rc = unet_workspace(&ws, sizeof(float) * (n_sync + 2 * (size_t)C * S), as_stream(s));
   if (rc) return rc;
-  return bn_train_launch(inputs, activations, weights, BN_batch_stats, BN_running_stats, C, HW, N, S, (float *)ws, s);
+  return bn_train_launch(inputs, activations, weights, BN_batch_stats, BN_running_stats, C, HW, N, S,
+                         (float *)ws + n_sync, n_sync ? (double *)ws : nullptr, s);
 }
 
 // ---- batch norm training forward for callers that must not allocate --------------------------------
@@ -661,10 +716,13 @@ int unet_batch_norm_train_noalloc_f32(const float *inputs, float *activations, c
                "unet_batch_norm_train_noalloc_f32: %d channels x %d slices need %lld scratch floats, the fixed "
                "scratch holds %d; use unet_batch_norm_train_f32",
                C, S, (long long)2 * C * S, UNET_BN_SCRATCH_FLOATS);
+  UNET_REQUIRE(!unet_bn_sync_on(), "unet_batch_norm_train_noalloc_f32: statistics synchronised across ranks "
+                                   "(unet_bn_set_sync) are not supported here; use unet_batch_norm_train_f32");
   float *scratch = nullptr;
   rc = bn_scratch_of_current_device(&scratch);
   if (rc) return rc;
-  return bn_train_launch(inputs, activations, weights, BN_batch_stats, BN_running_stats, C, HW, N, S, scratch, s);
+  return bn_train_launch(inputs, activations, weights, BN_batch_stats, BN_running_stats, C, HW, N, S, scratch, nullptr,
+                         s);
 }
 
 int unet_batch_norm_inference_f32(const float *inputs, float *activations, const float *weights,
@@ -689,19 +747,42 @@ int unet_batch_norm_backward_f32(const float *grad_activations, const float *inp
                "unet_batch_norm_backward_f32: NULL pointer");
   const i64 HW = (i64)H * W, M = HW * N;
   const int S = bn_splits(M, C);
+  const bool sync = unet_bn_sync_on();
+  const size_t n_sync = sync ? 4 * (size_t)C : 0;
   void *ws;
-  rc = unet_workspace(&ws, sizeof(float) * 2 * (size_t)C * S, as_stream(s));
+  rc = unet_workspace(&ws, sizeof(float) * (n_sync + 2 * (size_t)C * S), as_stream(s));
   if (rc) return rc;
+  float *partials = (float *)ws + n_sync;
+  int world = 1;
+  if (sync) {  // element count of the statistics: all ranks (the same count on every rank)
+    rc = unet_bn_sync_sum_f64(nullptr, 0, &world, as_stream(s));
+    if (rc) return rc;
+  }
+  const float Mg = (float)(M * world);
   hipLaunchKernelGGL(bn_partial_kernel<1>, dim3(S, C), dim3(256), 0, as_stream(s), inputs, grad_activations,
-                     BN_batch_stats, (float *)ws, C, HW, M, S);
+                     BN_batch_stats, partials, C, HW, M, S, Mg);
   UNET_LAUNCH_CHECK("bn_partial_kernel<1>");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)C), dim3(64), 0, as_stream(s), (const float *)ws,
-                     grad_weights, (float *)nullptr, C, S, (float)M);
-  UNET_LAUNCH_CHECK("bn_finalize_kernel");
+  if (sync) {
+    double *sums = (double *)ws;
+    hipLaunchKernelGGL(bn_finalize_f64_kernel, dim3((unsigned)C), dim3(64), 0, as_stream(s), (const float *)partials,
+                       sums, C, S);
+    UNET_LAUNCH_CHECK("bn_finalize_f64_kernel");
+    rc = unet_bn_sync_sum_f64(sums, 2 * (i64)C, &world, as_stream(s));
+    if (rc) return rc;
+    hipLaunchKernelGGL(bn_publish_kernel, dim3(cdiv_u(C, 64)), dim3(64), 0, as_stream(s), (const double *)sums,
+                       grad_weights, (float *)nullptr, C, Mg);
+    UNET_LAUNCH_CHECK("bn_publish_kernel");
+  } else {
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)C), dim3(64), 0, as_stream(s), (const float *)partials,
+                       grad_weights, (float *)nullptr, C, S, Mg);
+    UNET_LAUNCH_CHECK("bn_finalize_kernel");
+  }
   hipLaunchKernelGGL(bn_apply_kernel<2>, bn_apply_grid(HW, (i64)N * C), dim3(256), 0, as_stream(s), inputs,
                      grad_activations, grad_inputs, weights, BN_batch_stats, (const float *)grad_weights, C, HW,
-                     (i64)N * C, (float)M);
+                     (i64)N * C, Mg);
   UNET_LAUNCH_CHECK("bn_apply_kernel<2>");
+  // the gradient all-reduce takes the mean over ranks: hand it this rank's share of the global sums
+  if (sync && world > 1) return unet_scale_f32(grad_weights, 1.0f / (float)world, 2 * (i64)C, s);
   return UNET_OK;
 }
 

@@ -1,18 +1,24 @@
-"""Data-parallel training glue: one process per GPU, batch sharded across
-ranks, gradients averaged with torch.distributed (backend "nccl" is RCCL over
-xGMI on ROCm; "gloo" for CPU tests).
+"""Data-parallel training: one process per GPU, the batch sharded across ranks.
 
-The network keeps all gradients in one flat fp32 buffer, cut into buckets at
-layer boundaries and numbered in the order backward finishes them (last layer
-first).  Backward records one HIP event per bucket on the compute stream; the
-all-reduce of bucket b is enqueued on a separate communication stream that
-waits only for event b, so reduction of the late layers' gradients overlaps
-with the backward pass of the early layers.  The optimiser step waits for all
-buckets.
+The collective itself lives behind the C ABI (include/unet_hip.h, `unet_comm_*`, `unet_allreduce_begin/wait`:
+RCCL over xGMI).  The engine keeps all gradients in one flat fp32 buffer, cut into buckets at layer
+boundaries and numbered in the order backward finishes them (last layer first).  With a communicator
+attached (`net.set_comm`), backward records one HIP event per bucket on the compute stream and at once
+enqueues that bucket's mean over the ranks on the communicator's own stream, which waits only for that
+event; the reduction of the late layers' gradients therefore overlaps with the backward pass of the early
+layers, and the optimiser step waits for all buckets.  This module only bootstraps the communicator (the
+RCCL unique id travels over torch.distributed, whatever its backend) and shards batches.
 
-Batch-norm statistics are per rank (each rank normalises with its local batch),
-as in the usual non-synchronised data-parallel recipe.
+Batch-norm statistics are per rank by default (each rank normalises with its local batch, the usual
+non-synchronised recipe); `sync_bn=True` (or UNET_SYNC_BN=1) adds the per-channel sums over the ranks inside
+the batch-norm entry points, which makes an N-rank step equal to the single-GPU step on the whole batch.
+
+Where RCCL cannot connect the ranks (torch.distributed on "gloo": CPU tests, or several ranks sharing one
+GPU) the buckets are staged through host memory instead; everything else is the same code.
 """
+import ctypes
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -37,40 +43,41 @@ def shard_range(total, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def allreduce_mean_(flat, buckets, group=None, streams=None, force=False):
-    """In-place mean over ranks of `flat` (1-D tensor), bucket by bucket.
-
-    buckets: [(offset, count, event_handle_or_None)], processed in list order.
-    streams: None, or (comm_stream, wait_event_fn) -- each bucket's collective
-      is then enqueued on comm_stream after wait_event_fn(comm_stream, event).
-    force: run the collectives even in a one-rank group (exercises the transport).
-    Returns the list of work handles (already waited on when streams is None).
-    """
+def allreduce_mean_(flat, buckets, group=None):
+    """In-place mean over ranks of `flat` (1-D host or device tensor), bucket by bucket, through
+    torch.distributed (the host-staged transport and the CPU tests use it)."""
     world = dist.get_world_size(group)
-    if world == 1 and not force:
+    if world == 1:
         return []
-    use_avg = dist.get_backend(group) == "nccl"
-    op = dist.ReduceOp.AVG if use_avg else dist.ReduceOp.SUM
-    works = []
-    for off, cnt, ev in buckets:
+    for off, cnt, _ in buckets:
         view = flat[off:off + cnt]
-        if streams is not None:
-            comm, wait_event = streams
-            if ev:
-                wait_event(comm, ev)
-            with torch.cuda.stream(comm):
-                works.append(dist.all_reduce(view, op=op, group=group, async_op=True))
-        else:
-            dist.all_reduce(view, op=op, group=group)
-            if not use_avg:
-                view.div_(world)
-    return works
+        dist.all_reduce(view, op=dist.ReduceOp.SUM, group=group)
+        view.div_(world)
+    return []      # no work handles: every bucket is complete on return
+
+
+def init_comm(capi, group=None, device=None):
+    """Creates this rank's communicator of the C ABI; rank 0's unique id reaches the others through
+    torch.distributed.  Collective: every rank of `group` must call it."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    nbytes = capi.lib().unet_comm_unique_id_bytes()
+    buf = ctypes.create_string_buffer(nbytes)
+    if rank == 0:
+        capi.unet_comm_get_unique_id(buf)
+    box = [buf.raw if rank == 0 else None]
+    if world > 1:
+        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group,
+                                   device=device if dist.get_backend(group) == "nccl" else None)
+    ident = ctypes.create_string_buffer(box[0], nbytes)
+    comm = ctypes.c_void_p()
+    capi.unet_comm_init_rank(ctypes.byref(comm), ident, world, rank)
+    return comm
 
 
 class DataParallel:
-    """Wraps a created neural_net.NeuralNet for synchronous data-parallel SGD."""
+    """Wraps a created neural_net.NeuralNet for synchronous data-parallel training."""
 
-    def __init__(self, net, device, bucket_bytes=16 << 20, group=None, force_collectives=False):
+    def __init__(self, net, device, bucket_bytes=16 << 20, group=None, force_collectives=False, sync_bn=None):
         from unet_amd import capi
         self.net, self.device, self.group, self._capi = net, device, group, capi
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -81,29 +88,49 @@ class DataParallel:
         self.grads = tensor_from_ptr(net.gradients_ptr(), n, device)
         self.params = tensor_from_ptr(net.parameters_ptr(), n, device)
         self.force = bool(force_collectives) and dist.is_initialized()
-        self.comm = torch.cuda.Stream(device=device) if (self.world > 1 or self.force) else None
+        if sync_bn is None:
+            sync_bn = os.environ.get("UNET_SYNC_BN", "0") not in ("", "0")
+        self.sync_bn = bool(sync_bn)
+        self.comm = None
+        active = self.world > 1 or self.force
+        # RCCL needs one GPU per rank; "gloo" groups (CPU tests, ranks sharing a GPU) stage through the host
+        self.native = active and dist.get_backend(group) == "nccl"
+        if self.native:
+            if self.force:
+                os.environ["UNET_COMM_FORCE"] = "1"   # run the collectives even in a one-rank communicator
+            self.comm = init_comm(capi, group, device)
+            net.set_comm(self.comm.value)
+            if self.sync_bn:
+                capi.unet_bn_set_sync(self.comm)
+        elif self.sync_bn and active:
+            raise RuntimeError("sync_bn needs the RCCL transport (torch.distributed backend 'nccl')")
+
+    def close(self):
+        if self.comm is not None:
+            self.net.synchronize()
+            self.net.set_comm(0)
+            self._capi.unet_bn_set_sync(None)
+            self._capi.unet_comm_destroy(self.comm)
+            self.comm = None
 
     def broadcast_parameters(self, src=0):
-        if self.world > 1 or self.force:
+        """Rank `src`'s parameters (native transport: also running statistics and optimiser state) to all."""
+        if self.native:
+            self.net.broadcast_state(src)
             self.net.synchronize()
-            dist.broadcast(self.params, src, group=self.group)
+        elif self.world > 1:
+            self.net.synchronize()
+            host = self.params.cpu()
+            dist.broadcast(host, src, group=self.group)
+            self.params.copy_(host)
             torch.cuda.synchronize(self.device)
-
-    def _wait_event(self, stream, event):
-        self._capi.unet_stream_wait_event(stream.cuda_stream, event)
+            self.net.parameters_changed()
 
     def reduce_gradients(self):
-        """Averages the gradient buffer over the ranks, bucket by bucket, each
-        bucket as soon as backward has finished it."""
-        if self.world == 1 and not self.force:
+        """Host-staged transport only (the native one reduces inside backward): averages the gradient
+        buffer over the ranks, bucket by bucket, each bucket as soon as backward has finished it."""
+        if self.native or self.world == 1:
             return
-        if dist.get_backend(self.group) == "nccl":
-            works = allreduce_mean_(self.grads, self.buckets, self.group, (self.comm, self._wait_event), self.force)
-            for w in works:
-                w.wait()      # the compute stream waits for the reduced bucket
-            return
-        # Transports without device collectives (gloo, used by the single-GPU rehearsal of the
-        # multi-rank path): stage each finished bucket through host memory.
         for off, cnt, ev in self.buckets:
             if ev:
                 self._capi.unet_event_synchronize(ev)
@@ -115,8 +142,8 @@ class DataParallel:
         torch.cuda.synchronize(self.device)
 
     def train_step(self, images_ptr, masks_ptr, batch, lr):
-        """Enqueues forward, backward, the bucketed all-reduce and the Adam step
-        for this rank's shard (device pointers); does not synchronise."""
+        """Enqueues forward, backward (with the bucketed all-reduce) and the Adam step for this rank's
+        shard (device pointers); does not synchronise on the native transport."""
         self.net.forward_backward_device(images_ptr, masks_ptr, batch)
         self.reduce_gradients()
         self.net.step(lr)

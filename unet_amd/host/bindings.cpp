@@ -287,6 +287,11 @@ class NN {
       out.emplace_back(b[i].offset, b[i].count, reinterpret_cast<uintptr_t>(net_.bucket_event(i)));
     return out;
   }
+  // data-parallel training on a communicator of the C ABI (handle from unet_comm_init_rank; 0 = none)
+  void set_comm(uintptr_t comm) { net_.set_comm(reinterpret_cast<unet_comm_t>(comm)); }
+  void broadcast_state(int root) { net_.broadcast_state(root); }
+  // after writing through parameters_ptr(): packed weights and cached inference coefficients are stale
+  void parameters_changed() { net_.parameters_changed(); }
   float last_epoch_loss() const { return last_epoch_loss_; }
   std::string compute_dtype() const { return net_.is_bf16() ? "bf16" : "f32"; }
 
@@ -436,6 +441,9 @@ PYBIND11_MODULE(neural_net, m) {
       .def("synchronize", &NN::synchronize)
       .def("set_bucket_bytes", &NN::set_bucket_bytes)
       .def("gradient_buckets", &NN::gradient_buckets)
+      .def("set_comm", &NN::set_comm)
+      .def("broadcast_state", &NN::broadcast_state)
+      .def("parameters_changed", &NN::parameters_changed)
       .def("last_epoch_loss", &NN::last_epoch_loss)
       .def("compute_dtype", &NN::compute_dtype);
 

@@ -292,6 +292,7 @@ class Net {
     if (f.out_c != 1) throw std::runtime_error("the loss functions need a final layer with one output channel");
     for (Node &n : nodes_) n.grad_seen = false;
     next_bucket_ = 0;
+    if (comm_) UNET_CALL(unet_allreduce_wait(comm_, stream_));  // a reduction of the last step still in flight
     // loss gradient -> final layer's grad_out
     if (loss_ == LossFunction::kDiceLoss) {
       // L = 1 - mean_n dice_n  =>  dL/dp = -(1/N) * 2(mD - I)/D^2
@@ -321,6 +322,7 @@ class Net {
   // One Adam step over every parameter (cuda_ops.cu:405-471 semantics, one
   // step counter for the whole network).
   void step_device(float learning_rate) {
+    if (comm_) UNET_CALL(unet_allreduce_wait(comm_, stream_));  // every bucket's mean over the ranks has landed
     ++step_count_;
     UNET_CALL(unet_update_weights_adam_f32(params_.f32(), grads_.f32(), adam_.f32(), learning_rate,
                                            total_params_, step_count_, stream_));
@@ -554,6 +556,26 @@ class Net {
     return buckets_;
   }
   void *bucket_event(size_t i) { return bucket_events_.at(i); }
+  // Data-parallel training over a communicator of the C ABI (unet_comm_init_rank; NULL = single process):
+  // backward_device() then starts the all-reduce of every gradient bucket as it completes and
+  // step_device() waits for all of them.
+  void set_comm(unet_comm_t comm) { comm_ = comm; }
+  unet_comm_t comm() const { return comm_; }
+  // Rank `root`'s parameters, running statistics and optimiser state to every rank.
+  void broadcast_state(int root) {
+    if (!comm_) return;
+    UNET_CALL(unet_broadcast_f32(comm_, params_.f32(), total_params_, root, stream_));
+    UNET_CALL(unet_broadcast_f32(comm_, adam_.f32(), 2 * total_params_, root, stream_));
+    for (Node &n : nodes_)
+      if (n.has_params() && n.num_bn > 0) UNET_CALL(unet_broadcast_f32(comm_, n.running.f32(), n.num_bn, root, stream_));
+    parameters_changed();
+  }
+  // To be called after the parameter buffer (param_ptr()) was written from outside the engine: the packed
+  // bf16 weights and the cached inference batch-norm coefficients are rebuilt before their next use.
+  void parameters_changed() {
+    params_dirty_ = true;
+    inf_coef_valid_ = false;
+  }
 
   // ---- accessors -----------------------------------------------------------------
   bool created() const { return !nodes_.empty(); }
@@ -901,6 +923,11 @@ class Net {
     const std::vector<Bucket> &b = buckets();
     while (next_bucket_ < b.size() && b[next_bucket_].first_layer >= layer_done) {
       UNET_CALL(unet_event_record(bucket_events_[next_bucket_], stream_));
+      // data-parallel training: the bucket's mean over the ranks starts on the communication stream as soon
+      // as its last gradient is written, while backward goes on with the earlier layers
+      if (comm_)
+        UNET_CALL(unet_allreduce_begin(comm_, grads_.f32() + b[next_bucket_].offset, b[next_bucket_].count,
+                                       bucket_events_[next_bucket_]));
       ++next_bucket_;
     }
   }
@@ -1372,6 +1399,7 @@ class Net {
   std::vector<Bucket> buckets_;
   std::vector<void *> bucket_events_;
   size_t next_bucket_ = 0;
+  unet_comm_t comm_ = nullptr;
 };
 
 }  // namespace unet
