@@ -8,6 +8,7 @@
                the forward pass, and agreement with the engine's own fp32 path (which the small
                tests pin to the oracle) on loss and gradient direction.
 """
+import json
 import os
 
 import numpy as np
@@ -129,7 +130,9 @@ def test_config2_train_step_full_size_properties(nn, graph):
     ga = ga.astype(np.float64)
     assert abs(la - lf) <= 2e-2 * abs(lf), (la, lf)
     cos = lambda u, v: float(np.dot(u, v) / (np.linalg.norm(u) * np.linalg.norm(v)))
-    assert cos(ga, gf) >= 0.6, cos(ga, gf)
+    # noise floor of this comparison (bf16 storage vs none), measured on the float64 oracle by
+    # tools/bf16_grad_sensitivity.py: 0.72 over the whole gradient, 0.68 at the first layer, 0.99 at the last
+    assert cos(ga, gf) >= 0.65, cos(ga, gf)
     off, per_layer = 0, []
     for kind, sh, _, _ in graph:
         if kind in ("conv", "up"):
@@ -140,7 +143,7 @@ def test_config2_train_step_full_size_properties(nn, graph):
             assert 0.9 <= ratio <= 1.1, (kind, sh, ratio)
             off += nw + 3 * sh[3]
     assert per_layer[-1] >= 0.98 and per_layer[-2] >= 0.93, per_layer[-3:]
-    assert min(per_layer) >= 0.5, per_layer
+    assert min(per_layer) >= 0.6, per_layer
 
 
 def test_config2_shape_one_image_against_emulating_oracle(nn, graph):
@@ -166,8 +169,26 @@ def test_config2_shape_one_image_against_emulating_oracle(nn, graph):
     # through 23 batch norms that cancel most of it, so the remainder is sensitive to which
     # pre-activations round across zero; the small graphs of test_module_bf16_gpu.py hold the same
     # comparison to 0.99.
-    c = float(np.dot(g, ref_g) / (np.linalg.norm(g) * np.linalg.norm(ref_g)))
-    assert c >= 0.8, c
+    # The floor is measured, not assumed: tools/bf16_grad_sensitivity.py runs this float64 oracle against a copy
+    # of itself whose convolution outputs are moved by +-1 fp32 ulp before the bf16 rounding (two equally valid
+    # evaluations of the same network) and records how far their gradients drift apart per layer: 0.999 at the
+    # last layer down to 0.86 at the first, 0.866 over the whole gradient.  The engine has to agree with the
+    # oracle about as well as the oracle agrees with itself; a systematic error would push it well below.
+    noise = json.load(open(os.path.join(os.path.dirname(__file__), "..", "profiles",
+                                        "r2_bf16_grad_sensitivity_256.json")))["emulating_vs_nudged_1"]
+    cos = lambda u, v: float(np.dot(u, v) / (np.linalg.norm(u) * np.linalg.norm(v)))
+    c = cos(g, ref_g)
+    assert c >= noise["whole_gradient_cos"] - 0.05, (c, noise["whole_gradient_cos"])
+    off, li, report = 0, 0, []
+    for kind, sh, _, _ in graph:
+        if kind in ("conv", "up"):
+            nw = sh[2] * sh[3] * sh[4] * sh[4]
+            cl, floor = cos(g[off:off + nw], ref_g[off:off + nw]), noise["layers"][li]["cos"]
+            report.append((round(cl, 3), floor))
+            assert cl >= floor - 0.07, (li, kind, sh, cl, floor, report)
+            off += nw + 3 * sh[3]
+            li += 1
+    print("per-layer cosine (engine vs oracle, oracle vs nudged oracle):", report)
     # The engine's fp32 path on the same image against the plain float64 oracle: tight, which
     # pins the large-shape code paths (many tiles, split-K, 1024 channels) independently of bf16.
     f = _make(nn, graph, "fp32")
@@ -181,3 +202,28 @@ def test_config2_shape_one_image_against_emulating_oracle(nn, graph):
     c32 = float(np.dot(gf, g64) / (np.linalg.norm(gf) * np.linalg.norm(g64)))
     assert c32 >= 0.9999, c32
     assert np.linalg.norm(gf - g64) <= 1e-2 * np.linalg.norm(g64), np.linalg.norm(gf - g64) / np.linalg.norm(g64)
+
+
+def test_bf16_and_fp32_loss_trajectories_agree(nn):
+    """50 optimiser steps of the reference's own main.py graph (main.py:187-224) at 128 x 128, batch 4, on
+    the bf16 path and on the fp32 path from the same parameters and data: the loss of every step agrees to
+    2e-2 (the gradient noise that bf16 storage adds does not bias the optimisation)."""
+    hw, n, steps = 128, 4, 50
+    g = torch_ref.main_py_graph(hw, hw, 3, 64)
+    rng = np.random.default_rng(61)
+    x = rng.standard_normal((2 * n, 3, hw, hw)).astype(np.float32)
+    yy, xx = np.mgrid[0:hw, 0:hw]
+    m = np.stack([((yy - rng.integers(30, 98)) ** 2 + (xx - rng.integers(30, 98)) ** 2 < rng.integers(8, 24) ** 2)
+                  for _ in range(2 * n)]).astype(np.float32)
+    x[:, 0] += 2.0 * m      # the mask is visible in the image, so the loss falls
+    a, f = _make(nn, g, "bf16"), _make(nn, g, "fp32")
+    f.set_parameters(a.get_parameters())
+    la, lf = [], []
+    for t in range(steps):
+        lo = (t % 2) * n
+        la.append(a.train_step(x[lo:lo + n], m[lo:lo + n], 1e-3, True))
+        lf.append(f.train_step(x[lo:lo + n], m[lo:lo + n], 1e-3, True))
+    la, lf = np.asarray(la), np.asarray(lf)
+    assert np.isfinite(la).all() and np.isfinite(lf).all()
+    assert lf[-1] < lf[0] - 0.05, (lf[0], lf[-1])          # it does train
+    assert np.abs(la - lf).max() <= 2e-2, (np.abs(la - lf).max(), la[-5:], lf[-5:])

@@ -272,7 +272,17 @@ class _MaxPoolTies(torch.autograd.Function):
         return (x == up(y)).to(g.dtype) * up(g), None
 
 
-def forward(graph, params, x, training=True, running=None, emulate_bf16=False):
+def _ulp_nudge(z, gen):
+    """z moved by one fp32 unit in the last place, up or down at random per element (no gradient through
+    the nudge): the smallest difference two correct fp32 accumulations of the same sum can show."""
+    z32 = z.detach().to(torch.float32)
+    up = torch.rand(z32.shape, generator=gen) < 0.5
+    inf = torch.full_like(z32, float("inf"))
+    moved = torch.where(up, torch.nextafter(z32, inf), torch.nextafter(z32, -inf))
+    return z + (moved.to(z.dtype) - z.detach())
+
+
+def forward(graph, params, x, training=True, running=None, emulate_bf16=False, nudge_seed=None):
     """x float64 [N,C,H,W] -> list of per-layer activations.  `running`
     (optional list of [mean,var] interleaved arrays per layer) is used when
     training=False.
@@ -284,7 +294,12 @@ def forward(graph, params, x, training=True, running=None, emulate_bf16=False):
     rounded convolution output, attention gates compute in full precision
     on the rounded inputs and round their output, the final (narrow) layer's batch norm,
     activation and loss stay in full precision, and max pool routes gradients
-    to every tied maximum.  Arithmetic stays float64."""
+    to every tied maximum.  Arithmetic stays float64.
+
+    nudge_seed: every convolution output is moved by +-1 fp32 ulp (seeded, per element) before it is
+    rounded -- a second, equally valid evaluation of the same network, used to measure how far two correct
+    bf16 runs drift apart (tools/bf16_grad_sensitivity.py)."""
+    gen = None if nudge_seed is None else torch.Generator().manual_seed(int(nudge_seed))
     rnd = _RoundBF16.apply if emulate_bf16 else (lambda t: t)
     rndw = _RoundBF16Value.apply if emulate_bf16 else (lambda t: t)
     if emulate_bf16:
@@ -299,6 +314,8 @@ def forward(graph, params, x, training=True, running=None, emulate_bf16=False):
                 z = F.conv2d(inp, rndw(p["w"]).permute(1, 0, 2, 3), p["b"], stride=s[6], padding=s[5])
             else:
                 z = F.conv_transpose2d(inp, rndw(p["w"]), p["b"], stride=s[4])
+            if gen is not None:
+                z = _ulp_nudge(z, gen)
             z = rnd(z)
             if training:
                 y = F.batch_norm(z, None, None, p["gamma"], p["beta"], training=True, eps=BN_EPS)
