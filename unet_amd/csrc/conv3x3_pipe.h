@@ -1,0 +1,412 @@
+// Pipelined 3x3 / pad 1 / stride 1 bf16 convolution for gfx950: the kernel the convolution entry points use
+// for images of at least 32 rows and channel counts in multiples of 64 (conv_bf16.hip keeps the general one).
+//
+// What it changes against conv_mfma_kernel<9, 64, ...> (same MFMA loop, same LDS image, same summation order,
+// so the two kernels return bit-identical outputs):
+//   - a workgroup is PERSISTENT: 8 wavefronts own one block of 64 output channels and walk over many
+//     32 x 16 pixel tiles.  The stages of all its tiles (stage = one 32-channel K chunk of one tile) form one
+//     software pipeline: the operands of stage s+1 travel while stage s is on the matrix cores, including
+//     across tile boundaries, so a tile's first chunk is no longer fetched with nothing to overlap it -- the
+//     cost that dominated the full-resolution layers (two chunks per tile);
+//   - operands go from memory straight into LDS (buffer_load ... lds, 1 KiB per wave instruction, no staging
+//     registers, no ds_write pass): two stage buffers, ONE barrier per stage.  The XOR swizzle of the LDS
+//     image is applied to the per-lane source address, the LDS side of such a load being lane-linear;
+//     out-of-image halo pixels address beyond the buffer descriptor and arrive as zeros;
+//   - twice the pixels per weight slab (512 instead of 256), and with C_in <= 64 the workgroup's whole
+//     weight block (72 KiB) stays in LDS for all of its tiles: per tile only the halo (38 KiB a chunk) moves;
+//   - the epilogue has no barrier and no LDS round trip: every wave converts, stores and reduces its own
+//     8 x 16 pixel x 32 channel block (8-byte stores; batch-norm sums over the 16 pixel lanes by DPP row
+//     rotations), and writes its own row of partial sums.
+#pragma once
+#include "bf16_util.h"
+#ifndef PIPE_LAB_ABLATE
+#define PIPE_LAB_ABLATE 0  // laboratory builds only: 1 = no output stores, 2 = no MFMAs
+#endif
+
+namespace pipe {
+
+constexpr int TH = 32, TW = 16;                    // pixel tile
+constexpr int HR = TH + 2, HC = TW + 2;            // halo rows / columns
+constexpr int HALO_PIECES = HR * HC * 4;           // 16-byte pieces of one halo stage (64 B per pixel)
+constexpr int HALO_INSTR = (HALO_PIECES + 63) / 64;  // wave instructions (1 KiB each) that fill it
+constexpr int HALO_BYTES = HALO_INSTR * 1024;      // 39936: the last instruction's tail is padding
+constexpr int W_INSTR = 9 * 64 * 4 / 64;           // 36
+constexpr int W_BYTES = W_INSTR * 1024;            // 36864: 9 taps x 64 channels x 64 B
+constexpr int STAGE_BYTES = HALO_BYTES + W_BYTES;  // 76800
+constexpr int MAX_WS_CHUNKS = 2;                   // weights resident in LDS up to C_in = 64
+constexpr int LDS_BYTES = 2 * STAGE_BYTES;         // 153600 (resident weights: 2 * HALO_BYTES + 2 * W_BYTES)
+
+struct Args {
+  const bf16_t *in;
+  const bf16_t *wt;     // packed [C_in/32][9][CoP][32]
+  const float *bias;    // or null
+  bf16_t *out;
+  float *stats;         // [N][rows_per_image][CoP][2] or null; rows_per_image = 4 * tilesY * tilesX
+  int N, H, W, nk, CoP; // nk = K chunks of 32 channels
+  int in_ld, out_ld;
+  int in_c;             // > 0: channels present in memory (< 32, multiple of 8, nk == 1); the rest reads as zero
+  int tilesX, tilesY;
+  int units;            // N * tilesY * tilesX
+  int co_blocks;        // CoP / 64
+  int co_valid;
+  int accumulate;
+  // BRED: the output is the gradient of a BN + ReLU layer's output; bz = that layer's pre-BN tensor,
+  // bcf its per-channel records {a, b, mean, 1/sqrt(var+eps)}; stats receives (sum g*xhat, sum g),
+  // g = out * relu'(a*z + b).  Channels below bred_c0 take no part; bz, bcf and stats are indexed by
+  // (channel - bred_c0) and the stats rows hold CoP - bred_c0 channels.
+  const bf16_t *bz;
+  int bz_ld;
+  const float4 *bcf;
+  int bred_c0;
+  const float4 *affine;  // AFF: per-channel {a, b, ., .}: out = relu(a * (conv + bias) + b)
+};
+
+__device__ __forceinline__ float row_sum16(float v) {  // sum over the 16 lanes of a DPP row, in every lane
+  v = dpp_operand(v);
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xf, 0xf, true));
+  v = dpp_operand(v);
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124, 0xf, 0xf, true));
+  v = dpp_operand(v);
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x122, 0xf, 0xf, true));
+  v = dpp_operand(v);
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x121, 0xf, 0xf, true));
+  return v;
+}
+
+typedef __attribute__((address_space(3))) void *lds_ptr_t;
+
+// What the epilogue does with a finished tile (compile-time, so that each variant is straight-line code):
+enum Epi {
+  EPI_STATS = 0,  // forward in training: + bias, bf16 store, per-strip (sum, sum of squares) of the rounded values
+  EPI_PLAIN = 1,  // + bias (if any), bf16 store: data gradient without fusion, forward without statistics
+  EPI_ACC = 2,    // the result is added to what `out` holds (gradient fan-in)
+  EPI_BRED = 3,   // data gradient + the BN-backward pixel sums of the layer that produced the input
+  EPI_AFF = 4,    // inference: relu(a * (conv + bias) + b) with per-channel {a, b}
+};
+constexpr int epi_vmem_ops(int epi) {  // vector-memory instructions a wave issues per tile epilogue
+  return (epi == EPI_ACC || epi == EPI_BRED) ? 16 : 8;
+}
+
+// Lanes 16 apart exchange halves (v_permlane16_swap: odd 16-lane rows of the first operand <-> even rows of
+// the second).  In: hw[m] = the lane's 4 channels (2 dwords) of 16-channel block m, lane row kp holding
+// channels 4 kp .. 4 kp + 3.  Out: 16 bytes = 8 consecutive channels of block (kp & 1), from channel
+// 8 (kp >> 1).  The operands pass through a wait first (see dpp_operand): they come straight from VALU
+// conversions.  unswap16 is the inverse (the exchange is an involution).
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ i32x4 swap16(const u32x2_t (&hw)[2]) {
+  unsigned a0 = hw[0].x, a1 = hw[0].y, b0 = hw[1].x, b1 = hw[1].y;
+  asm volatile("s_nop 4" : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1));
+  const u32x2_t lo = __builtin_amdgcn_permlane16_swap(a0, b0, false, false);
+  const u32x2_t hi = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
+  return i32x4{(int)lo.x, (int)hi.x, (int)lo.y, (int)hi.y};
+}
+__device__ __forceinline__ void unswap16(const i32x4 &v, u32x2_t (&hw)[2]) {
+  unsigned p0 = (unsigned)v.x, p1 = (unsigned)v.y, q0 = (unsigned)v.z, q1 = (unsigned)v.w;
+  asm volatile("s_nop 4" : "+v"(p0), "+v"(p1), "+v"(q0), "+v"(q1));
+  const u32x2_t lo = __builtin_amdgcn_permlane16_swap(p0, q0, false, false);
+  const u32x2_t hi = __builtin_amdgcn_permlane16_swap(p1, q1, false, false);
+  hw[0] = u32x2_t{lo.x, hi.x};
+  hw[1] = u32x2_t{lo.y, hi.y};
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmem_then_barrier() {
+  // all but this wave's N youngest vector-memory operations are complete (the LDS loads of the stage about to
+  // be read are older than the N stores of a tile epilogue); own LDS reads are complete; then the barrier
+  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+
+template <bool WS, int EPI>
+__global__ __launch_bounds__(512, 2) void conv3x3_pipe_kernel(const Args a) {
+  constexpr bool BRED = EPI == EPI_BRED, AFF = EPI == EPI_AFF, STATS = EPI == EPI_STATS || EPI == EPI_BRED;
+  extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+  // WS: [halo 0][halo 1][weights chunk 0][weights chunk 1];  else: [halo 0][weights 0][halo 1][weights 1]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ph = wave & 3, cw = wave >> 2;
+  const int l15 = lane & 15, kp = lane >> 4;
+
+  const int cob = blockIdx.x % a.co_blocks, wgi = blockIdx.x / a.co_blocks, nwg = gridDim.x / a.co_blocks;
+  const int co0 = cob * 64;
+  const int my_units = wgi < a.units ? (a.units - wgi + nwg - 1) / nwg : 0;
+  if (my_units == 0) return;
+  const int tpi = a.tilesX * a.tilesY;
+
+  // ---- per-lane source plan of the LDS loads (fixed for the whole kernel) ----
+  // wave instruction i fills LDS bytes [1024 i, 1024 i + 1024) of its region; lane l's 16 bytes are LDS row
+  // r = 16 i + l / 4, slot l % 4, which the swizzled image assigns to piece slot ^ ((r >> 1) & 3) of row r
+  constexpr unsigned OOB = 0x80000000u;
+  int h_rel[5], h_pyx[5];   // halo: byte offset relative to the tile origin pixel; (py << 8) | px, or -1
+  unsigned w_rel[5];        // weights: byte offset within one chunk's slab
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    const int i = wave + 8 * k;
+    const int r = 16 * i + (lane >> 2), piece = (lane & 3) ^ ((r >> 1) & 3);
+    const int py = r / HC, px = r - py * HC;
+    const bool ok = i < HALO_INSTR && r < HR * HC && (a.in_c == 0 || piece * 8 < a.in_c);
+    h_rel[k] = (((py - 1) * a.W + (px - 1)) * a.in_ld + piece * 8) * 2;
+    h_pyx[k] = ok ? ((py << 8) | px) : -1;
+    const int j = (7 - wave) + 8 * k;  // the waves with one halo instruction fewer take one weight instruction more
+    const int rw = 16 * j + (lane >> 2), pw = (lane & 3) ^ ((rw >> 1) & 3);
+    const int tap = rw >> 6, co = rw & 63;
+    w_rel[k] = j < W_INSTR ? (unsigned)(((tap * a.CoP + co0 + co) * 32 + pw * 8) * 2) : OOB;
+  }
+  const unsigned img_bytes = (unsigned)a.H * a.W * a.in_ld * 2u;
+  const unsigned slab_bytes = 9u * a.CoP * 64u;  // one K chunk of the packed weights
+  const auto wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(a.wt), 0, slab_bytes * a.nk, 0x00020000);
+
+  auto unit_coords = [&](int it, int &n, int &y0, int &x0) {
+    const int u = wgi + it * nwg;
+    n = u / tpi;
+    const int t = u - n * tpi, ty = t / a.tilesX;
+    y0 = ty * TH;
+    x0 = (t - ty * a.tilesX) * TW;
+  };
+  auto issue_weights = [&](int kc, unsigned char *dst) {
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      const int j = (7 - wave) + 8 * k;
+      if (j < W_INSTR)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_ptr_t)(dst + j * 1024), 16, w_rel[k], kc * slab_bytes, 0, 0);
+    }
+  };
+  auto issue_halo = [&](int it, int kc, unsigned char *dst) {
+    int n, y0, x0;
+    unit_coords(it, n, y0, x0);
+    const auto xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(a.in) + (i64)n * a.H * a.W * a.in_ld, 0,
+                                                       img_bytes, 0x00020000);
+    const int org = ((y0 * a.W + x0) * a.in_ld + kc * 32) * 2;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      const int i = wave + 8 * k;
+      if (i < HALO_INSTR) {
+        const int py = h_pyx[k] >> 8, px = h_pyx[k] & 255;
+        const bool ok = h_pyx[k] >= 0 && (unsigned)(y0 + py - 1) < (unsigned)a.H && (unsigned)(x0 + px - 1) < (unsigned)a.W;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_ptr_t)(dst + i * 1024), 16, ok ? (unsigned)(org + h_rel[k]) : OOB,
+                                                 0, 0, 0);
+      }
+    }
+  };
+  auto halo_buf = [&](int s) { return lds + (WS ? (s & 1) * HALO_BYTES : (s & 1) * STAGE_BYTES); };
+  auto weight_buf = [&](int s, int kc) {
+    return WS ? lds + 2 * HALO_BYTES + kc * W_BYTES : lds + (s & 1) * STAGE_BYTES + HALO_BYTES;
+  };
+
+  // ---- fragment addresses (the LDS image and the loop of conv_mfma_kernel's 16x16x32 path) ----
+  const int a4_lane = l15 * 64 + ((kp ^ ((l15 >> 1) & 3)) * 16);
+  int b4_off[3][4];
+#pragma unroll
+  for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+    for (int rc = 0; rc < 4; ++rc) {
+      const int pl = rc * HC + l15 + kw;
+      b4_off[kw][rc] = (l15 + kw) * 64 + ((kp ^ ((pl >> 1) & 3)) * 16) + ph * 8 * HC * 64;
+    }
+
+  // ---- per-lane epilogue constants: the lane's 2 x 4 channels ----
+  f32x4 biasv[2], scalev[2];
+  float4 bcf[BRED ? 8 : 1];
+  const bool red_here = BRED && co0 >= a.bred_c0;  // uniform over the workgroup
+  const int rc0 = co0 - a.bred_c0;
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    const int ch = (cw * 2 + m) * 16 + 4 * kp;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float b = (!BRED && a.bias && co0 + ch + j < a.co_valid) ? a.bias[co0 + ch + j] : 0.f;
+      if (AFF) {
+        const float4 cf = a.affine[co0 + ch + j];
+        scalev[m][j] = cf.x;
+        biasv[m][j] = fmaf(cf.x, b, cf.y);
+      } else {
+        scalev[m][j] = 1.f;
+        biasv[m][j] = b;
+      }
+      if (BRED) bcf[BRED ? m * 4 + j : 0] = red_here ? a.bcf[rc0 + ch + j] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  const unsigned out_img_bytes = (unsigned)a.H * a.W * a.out_ld * 2u, z_img_bytes = (unsigned)a.H * a.W * a.bz_ld * 2u;
+  const int stat_width = BRED ? a.CoP - a.bred_c0 : a.CoP;  // channels per row of partial sums
+
+  const int nk = a.nk, S = my_units * nk;
+  if (WS)
+    for (int kc = 0; kc < nk; ++kc) issue_weights(kc, weight_buf(0, kc));
+  else
+    issue_weights(0, weight_buf(0, 0));
+  issue_halo(0, 0, halo_buf(0));
+
+  float ssum[2][4], ssq[2][4];  // batch-norm sums of this wave's channels over all tiles of the workgroup
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ssum[m][j] = ssq[m][j] = 0.f;
+
+  int s = 0;
+  for (int it = 0; it < my_units; ++it) {
+    f32x4 acc[2][8];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int q = 0; q < 8; ++q) acc[m][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int kc = 0; kc < nk; ++kc, ++s) {
+      // This wave's pieces of stage s have landed; after the barrier everybody's have, and everybody has
+      // finished reading the other buffer (stage s-1), which the next loads overwrite.  The first stage of
+      // a tile follows the previous tile's epilogue, whose stores were issued after these loads and need not
+      // be waited for.
+      if (kc == 0 && it > 0)
+        wait_vmem_then_barrier<epi_vmem_ops(EPI)>();
+      else
+        wait_vmem_then_barrier<0>();
+      if (s + 1 < S) {
+        const int it2 = (kc + 1 < nk) ? it : it + 1, kc2 = (kc + 1 < nk) ? kc + 1 : 0;
+        if (!WS) issue_weights(kc2, weight_buf(s + 1, kc2));
+        issue_halo(it2, kc2, halo_buf(s + 1));
+      }
+      const unsigned char *ldsX = halo_buf(s), *ldsW = weight_buf(s, kc);
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        bf16x8 brow[10];
+#pragma unroll
+        for (int r = 0; r < 10; ++r)
+          brow[r] = *reinterpret_cast<const bf16x8 *>(ldsX + r * HC * 64 + b4_off[kw][r & 3]);
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+          bf16x8 af[2];
+#pragma unroll
+          for (int m = 0; m < 2; ++m)
+            af[m] = *reinterpret_cast<const bf16x8 *>(ldsW + ((kh * 3 + kw) * 64 + (cw * 2 + m) * 16) * 64 + a4_lane);
+#pragma unroll
+          for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+#if PIPE_LAB_ABLATE == 2
+              if (a.N < 0)
+#endif
+              acc[m][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[m], brow[q + kh], acc[m][q], 0, 0, 0);
+        }
+      }
+    }
+
+    // ---- epilogue of tile `it`: every wave on its own 8 rows x 16 pixels x 32 channels.  Buffer loads and
+    // stores whose out-of-image lanes address beyond the descriptor: no branches, and a fixed number of
+    // vector-memory instructions per tile (epi_vmem_ops).  The matrix cores leave a lane with 4 channels of
+    // each of its two 16-channel blocks; v_permlane16_swap between lanes 16 apart turns that into 8
+    // consecutive channels of one block, so a lane moves 16 bytes and a pixel's 64 bytes leave in one piece.
+    int n, y0, x0;
+    unit_coords(it, n, y0, x0);
+    const int x = x0 + l15;
+    const i64 img = (i64)n * a.H * a.W;
+    const auto ors = __builtin_amdgcn_make_buffer_rsrc(a.out + img * a.out_ld, 0, out_img_bytes, 0x00020000);
+    const int ch16 = cw * 32 + (kp & 1) * 16 + (kp >> 1) * 8;  // first of the lane's 8 channels after the swap
+    unsigned ooff[8];  // byte offset of the lane's 16 bytes in the output image, or OOB
+    bool okq[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int y = y0 + ph * 8 + q;
+      okq[q] = y < a.H && x < a.W;
+      ooff[q] = okq[q] ? (unsigned)(((y * a.W + x) * a.out_ld + co0 + ch16) * 2) : OOB;
+    }
+    i32x4 zq[BRED ? 8 : 1], oq[EPI == EPI_ACC ? 8 : 1];
+    if (BRED) {  // the parent's pre-BN values (zeros for the channel half that takes no part)
+      const auto zrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(a.bz) + img * a.bz_ld, 0,
+                                                         red_here ? z_img_bytes : 0u, 0x00020000);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int y = y0 + ph * 8 + q;
+        const unsigned zo = okq[q] ? (unsigned)(((y * a.W + x) * a.bz_ld + rc0 + ch16) * 2) : OOB;
+        zq[BRED ? q : 0] = __builtin_amdgcn_raw_buffer_load_b128(zrs, zo, 0, 0);
+      }
+    }
+    if (EPI == EPI_ACC) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) oq[EPI == EPI_ACC ? q : 0] = __builtin_amdgcn_raw_buffer_load_b128(ors, ooff[q], 0, 0);
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      typedef u32x2_t u32x2;
+      u32x2 hw[2];   // the rounded result, matrix-core layout: hw[m] = 4 channels of block m
+      f32x4 rv[2];   // the same as floats (what the statistics see)
+      u32x2 ow[2] = {u32x2{0, 0}, u32x2{0, 0}}, zw[2] = {u32x2{0, 0}, u32x2{0, 0}};
+      if (EPI == EPI_ACC) unswap16(oq[EPI == EPI_ACC ? q : 0], ow);
+      if (BRED) unswap16(zq[BRED ? q : 0], zw);
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        f32x4 v = acc[m][q];
+        if (AFF) {
+          v = v * scalev[m] + biasv[m];
+          v = __builtin_elementwise_max(v, f32x4{0.f, 0.f, 0.f, 0.f});
+        } else if (!BRED) {
+          v += biasv[m];
+        }
+        bf16x4 h = __builtin_convertvector(v, bf16x4);
+        if (EPI == EPI_ACC)
+          h = __builtin_convertvector(__builtin_convertvector(h, f32x4) +
+                                          __builtin_convertvector(__builtin_bit_cast(bf16x4, ow[m]), f32x4), bf16x4);
+        hw[m] = __builtin_bit_cast(u32x2, h);
+        rv[m] = __builtin_convertvector(h, f32x4);
+      }
+      __builtin_amdgcn_raw_buffer_store_b128(swap16(hw), ors, ooff[q], 0, 0);
+      if (STATS) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+          f32x4 r = rv[m];  // statistics of the ROUNDED values
+          if (!okq[q]) r = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (BRED) {
+            const unsigned zz[2] = {zw[m].x, zw[m].y};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const float zv = (j & 1) ? bf16_to_f32(zz[j >> 1] >> 16) : bf16_to_f32(zz[j >> 1] & 0xffffu);
+              const float4 c = bcf[BRED ? m * 4 + j : 0];
+              const float g = fmaf(c.x, zv, c.y) > 0.f ? r[j] : 0.f;
+              ssum[m][j] = fmaf(g, zv, ssum[m][j]);  // sum g*z; turned into sum g*xhat at the end
+              ssq[m][j] += g;
+            }
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              ssum[m][j] += r[j];
+              ssq[m][j] += r[j] * r[j];
+            }
+          }
+        }
+      }
+    }
+  }
+  if (STATS && (!BRED || red_here)) {
+    // One row of partial sums per (workgroup, 8-row strip position): the sums ran over all tiles of the
+    // workgroup.  rows = 4 * (workgroups per channel block); lane 0 of each 16-lane row stores.
+    float *row = a.stats + ((i64)(wgi * 4 + ph) * stat_width + (BRED ? rc0 : co0)) * 2;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      float o[8];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float sv = row_sum16(ssum[m][j]), qv = row_sum16(ssq[m][j]);
+        if (BRED) sv = (sv - bcf[BRED ? m * 4 + j : 0].z * qv) * bcf[BRED ? m * 4 + j : 0].w;
+        o[2 * j] = sv;
+        o[2 * j + 1] = qv;
+      }
+      if (l15 == 0) {
+        float *dst = row + ((cw * 2 + m) * 16 + 4 * kp) * 2;
+        *reinterpret_cast<float4 *>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+        *reinterpret_cast<float4 *>(dst + 4) = make_float4(o[4], o[5], o[6], o[7]);
+      }
+    }
+  }
+}
+
+// Launch plan: persistent workgroups, a multiple of the channel-block count, at most one per tile and channel block.
+inline int plan_grid(int N, int H, int W, int CoP, int max_wgs = 256) {
+  const int co_blocks = CoP / 64, units = N * ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
+  int per_block = max_wgs / co_blocks;
+  if (per_block < 1) per_block = 1;
+  if (per_block > units) per_block = units;
+  return per_block * co_blocks;
+}
+// Rows of partial sums the kernel writes (in all, not per image): four per workgroup of a channel block.
+inline int stat_rows(int N, int H, int W, int CoP, int max_wgs = 256) { return 4 * (plan_grid(N, H, W, CoP, max_wgs) / (CoP / 64)); }
+
+// Whether the pipelined kernel serves this shape (the choice must not depend on the batch size).
+inline bool eligible(int H, int W, int CiP, int CoP) { return H >= 32 && W >= 16 && CoP % 64 == 0 && CiP % 32 == 0; }
+
+}  // namespace pipe
