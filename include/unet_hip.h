@@ -388,11 +388,15 @@ int unet_nhwc_bf16_to_nchw_f32(const uint16_t *in, float *out, int N, int C, int
  * (cudaConvolve, and with w_bwd / bias = NULL the data-gradient half of
  * cudaConvolveBackward).  out = conv(in) + bias, rounded to bf16; when
  * accumulate != 0 the result is added to what `out` holds (gradient fan-in).
- * stat_partials (optional) receives [N][tiles][CoP][2] per-tile (sum, sum of
- * squares) of the rounded outputs, tiles = unet_conv3x3_stat_tiles(H, W). */
+ * stat_partials (optional) receives rows of partial sums [rows][CoP][2] = (sum, sum of squares) of the
+ * rounded outputs over disjoint sets of pixels, rows = unet_conv3x3_stat_rows(N, H, W, CiP, CoP) -- how the
+ * pixels are grouped into rows depends on the kernel that serves the shape; consumers add the rows up
+ * (unet_bn_finalize_bf16).  unet_conv3x3_stat_tiles(H, W) = number of 16x16 pixel tiles of one image (the
+ * row count per image and phase of the transposed-convolution entry points). */
 int unet_conv3x3_bf16(const uint16_t *in, int in_ld, const uint16_t *w_packed, const float *bias, int co_valid,
                       uint16_t *out, int out_ld, float *stat_partials, int N, int H, int W, int CiP, int CoP,
                       int accumulate, unet_stream_t stream);
+int unet_conv3x3_stat_rows(int N, int H, int W, int CiP, int CoP);
 int unet_conv3x3_stat_tiles(int H, int W);
 /* Inference: the same convolution with the batch norm (running statistics) and ReLU that follow it folded into the
  * epilogue (cudaConvolve + cudaBatchNormInference + cudaRelu in one kernel): out = relu(a*(conv + bias) + b) with
@@ -424,8 +428,9 @@ int unet_conv3x3_head_wgrad_bf16(const float *dz, const uint16_t *x, int x_ld, f
 /* Data gradient of a 3x3 convolution whose INPUT is the output of a BN + ReLU
  * layer (fuses the first pass of cudaBatchNormBackward for that layer into the
  * data-gradient half of cudaConvolveBackward).  dx = conv(dz, w_packed_bwd) is
- * written (not accumulated), and red_partials receives [N][tiles][CoP][2]
- * per-tile (sum g*xhat, sum g) with g = dx * relu'(a*z+b), where bn_z is that
+ * written (not accumulated), and red_partials receives
+ * unet_conv3x3_stat_rows(N, H, W, CiP, CoP) rows [CoP][2] of partial sums
+ * (sum g*xhat, sum g) with g = dx * relu'(a*z+b), where bn_z is that
  * layer's pre-BN tensor and bn_coef its unet_bn_finalize_bf16 records; feed
  * them to unet_bn_act_backward_from_partials_bf16.  When the input is a concat
  * and only its second half comes from such a layer, bn_first_channel is the

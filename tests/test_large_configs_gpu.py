@@ -85,17 +85,23 @@ def test_conv3x3_beyond_2_31_elements(capi, big):
     bias = torch.randn(co, generator=g, device=DEV)
     fwd = torch.zeros(9 * co * c, dtype=torch.bfloat16, device=DEV)
     capi.unet_pack_weights_bf16(p(w), p(fwd), None, c, co, c, co, 3, None)
-    tiles = capi.lib().unet_conv3x3_stat_tiles(hw, hw)
+    rows, rows1 = capi.lib().unet_conv3x3_stat_rows(n, hw, hw, c, co), capi.lib().unet_conv3x3_stat_rows(1, hw, hw, c, co)
     out = torch.full((n, hw, hw, co), float("nan"), dtype=torch.bfloat16, device=DEV)
-    stats = torch.full((n, tiles, co, 2), float("nan"), device=DEV)
+    stats = torch.full((rows, co, 2), float("nan"), device=DEV)
     capi.unet_conv3x3_bf16(p(big), c, p(fwd), p(bias), co, p(out), co, p(stats), n, hw, hw, c, co, 0, None)
     out1 = torch.full((1, hw, hw, co), float("nan"), dtype=torch.bfloat16, device=DEV)
-    stats1 = torch.full((1, tiles, co, 2), float("nan"), device=DEV)
+    stats1 = torch.full((rows1, co, 2), float("nan"), device=DEV)
     capi.unet_conv3x3_bf16(p(big[n - 1]), c, p(fwd), p(bias), co, p(out1), co, p(stats1), 1, hw, hw, c, co, 0, None)
     torch.cuda.synchronize()
     assert torch.isfinite(out1.float()).all()
     assert torch.equal(out[n - 1].view(torch.int16), out1[0].view(torch.int16))
-    assert torch.equal(stats[n - 1], stats1[0])
+    # the batch-norm partial sums add up to the sums of the output tensor, for the batch and for the last image
+    for st, o in ((stats, out), (stats1, out1)):
+        tot = st.double().sum(dim=0)
+        want = torch.stack([o[i].double().sum(dim=(0, 1)) for i in range(o.shape[0])]).sum(dim=0)
+        want2 = torch.stack([(o[i].double() ** 2).sum(dim=(0, 1)) for i in range(o.shape[0])]).sum(dim=0)
+        assert torch.allclose(tot[:, 0], want, rtol=1e-4, atol=1e-2 * float(want2.max()) ** 0.5)
+        assert torch.allclose(tot[:, 1], want2, rtol=1e-4)
     # and the first image too (offsets far below 2^31): rules out a wrap-around that lands on image 0
     capi.unet_conv3x3_bf16(p(big), c, p(fwd), p(bias), co, p(out1), co, p(stats1), 1, hw, hw, c, co, 0, None)
     torch.cuda.synchronize()

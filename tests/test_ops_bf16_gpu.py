@@ -84,6 +84,11 @@ CONV_CASES = [
     (1, 64, 128, 40, 72),    # ragged tiles, 2 K chunks, 2 channel blocks
     (1, 32, 64, 80, 80),     # one K chunk
     (1, 128, 64, 72, 72),    # 4 K chunks; data gradient with 2 channel blocks
+    # the pipelined persistent kernel (images of 32 rows and more, 64-channel blocks): ragged 32x16 tiles, several
+    # images per workgroup, weights resident in LDS (C_in = 64) and streamed per stage (C_in = 96: three chunks)
+    (3, 64, 64, 50, 30),
+    (2, 96, 192, 33, 47),
+    (5, 64, 128, 64, 64),    # more tiles than workgroups per channel block
 ]
 
 
@@ -101,9 +106,9 @@ def test_conv3x3_forward_dgrad_wgrad(G, capi, oracle, cfg):
     xt = to_nhwc(G, capi, x)
     fwd, bwd = pack(G, capi, wt, ci, co, 3)
     bd = G.dev(bias)
-    tiles = capi.lib().unet_conv3x3_stat_tiles(h, w)
+    rows = capi.lib().unet_conv3x3_stat_rows(n, h, w, cip, cop)
     out = torch.full((n, h, w, cop), float("nan"), dtype=torch.bfloat16, device=G.DEV)
-    stats = G.empty((n, tiles, cop, 2))
+    stats = G.empty((rows, cop, 2))
     capi.unet_conv3x3_bf16(G.p(xt), cip, G.p(fwd), G.p(bd), co, G.p(out), cop, G.p(stats), n, h, w, cip, cop, 0, None)
     y = from_nhwc(G, capi, out, co)
     y_ref = oracle.convolve(x, w_and_b, co, 3, 1, 1)
@@ -111,7 +116,7 @@ def test_conv3x3_forward_dgrad_wgrad(G, capi, oracle, cfg):
     outh = out.float().cpu().numpy()
     assert np.all(outh[..., co:] == 0), "padded output channels must be zero"
     # statistics are sums of the ROUNDED outputs
-    st = G.host(stats).sum(axis=(0, 1))
+    st = G.host(stats).sum(axis=0)
     assert_close(st[:co, 0], y.sum(axis=(0, 2, 3)), rtol=1e-4, atol_scale=1e-5, what="conv stats sum")
     assert_close(st[:co, 1], (y.astype(np.float64) ** 2).sum(axis=(0, 2, 3)), rtol=1e-4, atol_scale=1e-5,
                  what="conv stats sum of squares")
@@ -367,7 +372,8 @@ def test_bn_act_with_fused_max_pool_forward_and_backward(G, capi, oracle, cfg):
 
 
 @pytest.mark.parametrize("cfg", [("conv", 2, 64, 64, 24, 40), ("conv", 1, 32, 96, 16, 16), ("tconv", 2, 64, 32, 8, 12),
-                                 ("conv", 1, 64, 64, 72, 80)])   # the last one runs the 16x16x32 main loop
+                                 ("conv", 1, 64, 64, 72, 80),    # the pipelined kernel, weights resident
+                                 ("conv", 3, 128, 192, 40, 48)])  # the pipelined kernel, six K chunks, two channel blocks
 def test_dgrad_with_fused_bn_backward_reduction(G, capi, cfg):
     """The data-gradient kernels that also reduce the parent's batch-norm backward over the pixels:
     dx is bit-identical to the plain data gradient, and dz / dgamma / dbeta / dbias agree with the
@@ -387,13 +393,15 @@ def test_dgrad_with_fused_bn_backward_reduction(G, capi, cfg):
     coef = G.dev(coef_h.reshape(-1))
     pixels = n * h * w
     tiles = capi.lib().unet_conv3x3_stat_tiles(h, w)
+    # rows of partial sums the fused data-gradient entry point writes
+    nrows = capi.lib().unet_conv3x3_stat_rows(n, h, w, cn, cp) if kind == "conv" else n * tiles
 
     def run(fused):
         dx = torch.zeros((n, h, w, cp), dtype=torch.bfloat16, device=G.DEV)
         dzp = torch.zeros((n, h, w, cp), dtype=torch.bfloat16, device=G.DEV)
         ggb, gbias = G.empty((2 * cp,)), G.empty((cp,))
         if fused:
-            parts = G.empty((n * tiles * cp * 2,))
+            parts = G.empty((nrows * cp * 2,))
             if kind == "conv":
                 capi.unet_conv3x3_dgrad_bnred_bf16(G.p(dzn), cn, G.p(wb), G.p(dx), cp, G.p(zp), cp, G.p(coef), G.p(parts), 0,
                                                    n, h, w, cn, cp, None)
@@ -401,7 +409,7 @@ def test_dgrad_with_fused_bn_backward_reduction(G, capi, cfg):
                 capi.unet_tconv2x2_dgrad_bnred_bf16(G.p(dzn), cn, G.p(wb), G.p(dx), cp, G.p(zp), cp, G.p(coef),
                                                     G.p(parts), n, h, w, cp, cn, None)
             capi.unet_bn_act_backward_from_partials_bf16(G.p(dx), cp, G.p(zp), cp, G.p(coef), G.p(gb), G.p(parts),
-                                                         n * tiles, G.p(dzp), cp, G.p(ggb), G.p(gbias), cp, cp, pixels, None)
+                                                         nrows, G.p(dzp), cp, G.p(ggb), G.p(gbias), cp, cp, pixels, None)
         else:
             if kind == "conv":
                 capi.unet_conv3x3_bf16(G.p(dzn), cn, G.p(wb), None, 0, G.p(dx), cp, None, n, h, w, cn, cp, 0, None)
@@ -417,15 +425,19 @@ def test_dgrad_with_fused_bn_backward_reduction(G, capi, cfg):
     assert np.abs(dx_a).max() > 0
     np.testing.assert_array_equal(dx_a, dx_b)
     assert_close(ggb_b, ggb_a, rtol=1e-4, atol_scale=1e-5, what="dgamma/dbeta")
-    assert_close(gbias_b, gbias_a, rtol=1e-3, atol_scale=1e-4, what="dbias")
-    # dz is bf16: the two paths may differ by one rounding where the fp32 value sits on a boundary
+    # dz is bf16: the two paths may differ by one rounding where the fp32 value sits on a boundary, and the bias
+    # gradient is the sum of the rounded values, so it may differ by a few units in the last place of the
+    # largest dz
     assert_close_bf16(dz_b, dz_a, what="dz")
+    ulp = float(np.abs(dz_a).max()) * 2.0 ** -8
+    assert np.abs(gbias_b - gbias_a).max() <= 1e-3 * np.abs(gbias_a).max() + 4 * ulp, np.abs(gbias_b - gbias_a).max()
 
 
-def test_dgrad_fused_reduction_on_second_half_of_a_concat(G, capi):
+@pytest.mark.parametrize("hw", [(24, 16), (40, 48)])   # the general kernel; the pipelined one
+def test_dgrad_fused_reduction_on_second_half_of_a_concat(G, capi, hw):
     """bn_first_channel = 64 of 128 output channels: the first half of dx is a plain data gradient,
     the second half also yields the BN-backward partial sums of the layer that produced it."""
-    n, cn, h, w, c1, c2 = 2, 64, 24, 16, 64, 64
+    n, cn, (h, w), c1, c2 = 2, 64, hw, 64, 64
     cp = c1 + c2
     rng = np.random.default_rng(12)
     dzn = torch.from_numpy(rng.standard_normal((n, h, w, cn)).astype(np.float32)).to(G.DEV).bfloat16()
@@ -435,11 +447,11 @@ def test_dgrad_fused_reduction_on_second_half_of_a_concat(G, capi):
     gb = G.dev((rng.random(2 * c2) + 0.5).astype(np.float32))
     coef = G.dev(np.stack([rng.random(c2) + 0.5, rng.standard_normal(c2) * 0.3, rng.standard_normal(c2) * 0.1,
                            rng.random(c2) + 0.7], axis=1).astype(np.float32).reshape(-1))
-    pixels, tiles = n * h * w, capi.lib().unet_conv3x3_stat_tiles(h, w)
+    pixels, nrows = n * h * w, capi.lib().unet_conv3x3_stat_rows(n, h, w, cn, cp)
     dx_a = torch.zeros((n, h, w, cp), dtype=torch.bfloat16, device=G.DEV)
     dx_b = torch.zeros_like(dx_a)
     capi.unet_conv3x3_bf16(G.p(dzn), cn, G.p(wb), None, 0, G.p(dx_a), cp, None, n, h, w, cn, cp, 0, None)
-    parts = G.empty((n * tiles * c2 * 2,))
+    parts = G.empty((nrows * c2 * 2,))
     capi.unet_conv3x3_dgrad_bnred_bf16(G.p(dzn), cn, G.p(wb), G.p(dx_b), cp, G.p(zu), c2, G.p(coef), G.p(parts), c1,
                                        n, h, w, cn, cp, None)
     torch.cuda.synchronize()
@@ -451,7 +463,7 @@ def test_dgrad_fused_reduction_on_second_half_of_a_concat(G, capi):
         dy_slice = dx_a.data_ptr() + 2 * c1         # channels [c1, c1+c2) of the concat gradient, pixel stride cp
         if fused:
             capi.unet_bn_act_backward_from_partials_bf16(dy_slice, cp, G.p(zu), c2, G.p(coef), G.p(gb), G.p(parts),
-                                                         n * tiles, G.p(dzu), c2, G.p(ggb), G.p(gbias), c2, c2, pixels, None)
+                                                         nrows, G.p(dzu), c2, G.p(ggb), G.p(gbias), c2, c2, pixels, None)
         else:
             capi.unet_bn_act_backward_bf16(dy_slice, cp, None, 0, G.p(zu), c2, G.p(coef), G.p(gb), G.p(dzu), c2, G.p(ggb),
                                            G.p(gbias), c2, c2, pixels, 0, None)
@@ -575,11 +587,12 @@ def test_first_layer_with_8_stored_channels(G, capi, oracle):
     np.testing.assert_array_equal(gws[0], gws[1])
 
 
-@pytest.mark.parametrize("kind", ["conv", "tconv"])
-def test_inference_bn_relu_folded_into_the_epilogue(G, capi, oracle, kind):
+@pytest.mark.parametrize("kind,shape", [("conv", (2, 64, 96, 20, 24)), ("tconv", (2, 64, 96, 20, 24)),
+                                        ("conv", (2, 64, 128, 40, 24))])   # the last: the pipelined kernel
+def test_inference_bn_relu_folded_into_the_epilogue(G, capi, oracle, kind, shape):
     """Inference: conv / transposed conv with BN (running statistics) + ReLU folded in, against the oracle's
     convolution -> bn_inference -> relu, and against the unfused pair of entry points."""
-    n, ci, co, h, w = 2, 64, 96, 20, 24
+    n, ci, co, h, w = shape
     cip, cop = pad32(ci), pad32(co)
     k = 3 if kind == "conv" else 2
     rng = np.random.default_rng(31)
@@ -632,10 +645,11 @@ def test_fused_bn_reduction_is_bit_identical_between_runs(G, capi, kind):
                        rng.random(cp) + 0.7], axis=1).astype(np.float32)
     coef = G.dev(coef_h.reshape(-1))
     tiles = capi.lib().unet_conv3x3_stat_tiles(h, w)
+    nrows = capi.lib().unet_conv3x3_stat_rows(n, h, w, cn, cp) if kind == "conv" else n * tiles
     outs = []
     for _ in range(5):
         dx = torch.zeros((n, h, w, cp), dtype=torch.bfloat16, device=G.DEV)
-        parts = G.empty((n * tiles * cp * 2,))
+        parts = G.empty((nrows * cp * 2,))
         if kind == "conv":
             capi.unet_conv3x3_dgrad_bnred_bf16(G.p(dzn), cn, G.p(wb), G.p(dx), cp, G.p(zp), cp, G.p(coef), G.p(parts), 0,
                                                n, h, w, cn, cp, None)

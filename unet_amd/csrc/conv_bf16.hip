@@ -27,6 +27,7 @@
 // maps -- the four (i,j) phases of the 2x2 stride-2 transposed convolution.
 //
 #include "bf16_util.h"
+#include "conv3x3_pipe.h"
 
 namespace {
 
@@ -446,7 +447,10 @@ int launch_conv(const ConvArgs &a, hipStream_t s) {
   return UNET_OK;
 }
 
+int launch_pipe_from(const ConvArgs &c, hipStream_t s);
+
 int launch_conv_any(int taps, const ConvArgs &a, hipStream_t s) {
+  if (taps == 9 && pipe::eligible(a.Ho, a.Wo, a.Ci, a.CoP) && !(a.accumulate && a.stats)) return launch_pipe_from(a, s);
   const bool wide = a.CoP % 64 == 0, deep = a.Ci % 64 == 0;
   // the 16x16x32 path for all but the smallest images (at batch 16: wherever a launch has more than one workgroup
   // per CU).  The choice must not depend on the batch size: the two loops add in different orders, and inference
@@ -467,6 +471,44 @@ int launch_conv_any(int taps, const ConvArgs &a, hipStream_t s) {
   if (taps == 9) return wide ? launch_conv<9, 64, false>(a, s) : launch_conv<9, 32, false>(a, s);
   if (wide) return deep ? launch_conv<1, 64, false, 64>(a, s) : launch_conv<1, 64, false>(a, s);
   return launch_conv<1, 32, false>(a, s);
+}
+
+// The pipelined persistent kernel (conv3x3_pipe.h) for the shapes it serves; returns false when the shape
+// stays with conv_mfma_kernel.  Which kernel runs depends on the image and channel sizes only, never on the
+// batch (both add in the same order anyway: their outputs are bit-identical).
+template <bool WS, int EPI>
+int launch_pipe(const pipe::Args &a, int grid, hipStream_t s) {
+  static bool attr_set[64] = {};
+  int dev = 0;
+  UNET_HIP_TRY(hipGetDevice(&dev));
+  if (!attr_set[dev & 63]) {
+    UNET_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&pipe::conv3x3_pipe_kernel<WS, EPI>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, pipe::LDS_BYTES));
+    attr_set[dev & 63] = true;
+  }
+  hipLaunchKernelGGL((pipe::conv3x3_pipe_kernel<WS, EPI>), dim3((unsigned)grid), dim3(512), pipe::LDS_BYTES, s, a);
+  UNET_LAUNCH_CHECK("conv3x3_pipe_kernel");
+  return UNET_OK;
+}
+template <int EPI>
+int launch_pipe_ws(const pipe::Args &a, int grid, hipStream_t s) {
+  return a.nk <= pipe::MAX_WS_CHUNKS ? launch_pipe<true, EPI>(a, grid, s) : launch_pipe<false, EPI>(a, grid, s);
+}
+int launch_pipe_from(const ConvArgs &c, hipStream_t s) {
+  pipe::Args a{};
+  a.in = c.in; a.wt = c.wt; a.bias = c.bias; a.out = c.out; a.stats = c.stats;
+  a.N = c.N; a.H = c.Ho; a.W = c.Wo; a.nk = c.Ci / 32; a.CoP = c.CoP;
+  a.in_ld = c.in_ld; a.out_ld = c.out_ld; a.in_c = c.in_c;
+  a.tilesX = (c.Wo + pipe::TW - 1) / pipe::TW; a.tilesY = (c.Ho + pipe::TH - 1) / pipe::TH;
+  a.units = c.N * a.tilesX * a.tilesY; a.co_blocks = c.CoP / 64; a.co_valid = c.co_valid;
+  a.accumulate = c.accumulate;
+  a.bz = c.bz; a.bz_ld = c.bz_ld; a.bcf = c.bcf; a.bred_c0 = c.bred_c0; a.affine = c.affine;
+  const int grid = pipe::plan_grid(c.N, c.Ho, c.Wo, c.CoP);
+  if (c.affine) return launch_pipe_ws<pipe::EPI_AFF>(a, grid, s);
+  if (c.bz) return launch_pipe_ws<pipe::EPI_BRED>(a, grid, s);
+  if (c.accumulate) return launch_pipe_ws<pipe::EPI_ACC>(a, grid, s);
+  if (c.stats) return launch_pipe_ws<pipe::EPI_STATS>(a, grid, s);
+  return launch_pipe_ws<pipe::EPI_PLAIN>(a, grid, s);
 }
 
 // ---------------------------------------------------------------------------
@@ -732,6 +774,12 @@ int unet_conv3x3_bn_relu_bf16(const uint16_t *in, int in_ld, const uint16_t *w_p
 }
 
 int unet_conv3x3_stat_tiles(int H, int W) { return ((H + 15) / 16) * ((W + 15) / 16); }
+
+int unet_conv3x3_stat_rows(int N, int H, int W, int CiP, int CoP) {
+  if (CiP < 32) CiP = 32;
+  if (pipe::eligible(H, W, CiP, CoP)) return pipe::stat_rows(N, H, W, CoP);
+  return N * unet_conv3x3_stat_tiles(H, W);
+}
 
 int unet_conv3x3_dgrad_bnred_bf16(const uint16_t *dz, int dz_ld, const uint16_t *w_packed_bwd, uint16_t *dx,
                                   int dx_ld, const uint16_t *bn_z, int bn_z_ld, const float *bn_coef,

@@ -934,6 +934,10 @@ class Net {
 
   // ======================= bf16 / NHWC compute path ============================
   static int pad32(int c) { return (c + 31) / 32 * 32; }
+  // rows of partial sums the 3x3 convolution entry points write for a call of this shape
+  static int conv_stat_rows(int batch, int h, int w, int cip, int cop) {
+    return unet_conv3x3_stat_rows(batch, h, w, cip, cop);
+  }
 
   // Decides whether the graph can run on the bf16 kernels and, if so, lays out
   // the activations: a layer feeding a CONCAT writes straight into its slice of
@@ -1014,9 +1018,16 @@ class Net {
         n.coef.ensure(sizeof(float) * (size_t)unet_bn_coef_floats(n.cop));
         n.coef_inf.ensure(sizeof(float) * (size_t)unet_bn_coef_floats(n.cop));
         const size_t in_pix_tiles = (size_t)unet_conv3x3_stat_tiles(n.in_h, n.in_w);
-        const size_t parts = n.type == CONV_LAYER ? b * in_pix_tiles : 4 * b * in_pix_tiles;
+        const size_t parts = n.type == CONV_LAYER ? (size_t)conv_stat_rows(batch, n.in_h, n.in_w, n.cip, n.cop)
+                                                  : 4 * b * in_pix_tiles;
         n.stat_partials.ensure(sizeof(float) * parts * n.cop * 2);
-        n.bwd_partials.ensure(sizeof(float) * b * (size_t)unet_conv3x3_stat_tiles(n.out_h, n.out_w) * n.cop * 2);
+        // BN-backward sums arrive from the consumer's data-gradient kernel (a 3x3 convolution over this
+        // layer's output grid, a transposed convolution whose input grid it is, or the head): room for the
+        // larger of the row counts those kernels use
+        const size_t strips = b * (size_t)((n.out_h + 31) / 32) * ((n.out_w + 15) / 16);
+        const size_t bwd_rows = std::max<size_t>(b * (size_t)unet_conv3x3_stat_tiles(n.out_h, n.out_w),
+                                                 std::min<size_t>(4 * strips, 1024));
+        n.bwd_partials.ensure(sizeof(float) * bwd_rows * n.cop * 2);
         max_dz = std::max(max_dz, 2 * pix * n.cop);
         const size_t taps = n.type == CONV_LAYER ? 9 : 4;
         n.w_fwd.ensure(2 * taps * (size_t)n.cop * n.cip);
@@ -1123,7 +1134,7 @@ class Net {
         } else if (n.type == CONV_LAYER) {
           UNET_CALL(unet_conv3x3_bf16(in, in_ld, n.w_fwd.u16(), bias, n.out_c, n.zb.u16(), n.cop, parts, batch, n.in_h,
                                       n.in_w, in_cip, n.cop, 0, stream_));
-          num_parts = batch * unet_conv3x3_stat_tiles(n.in_h, n.in_w);
+          num_parts = conv_stat_rows(batch, n.in_h, n.in_w, n.cip, n.cop);
         } else {
           UNET_CALL(unet_tconv2x2_bf16(in, in_ld, n.w_fwd.u16(), bias, n.out_c, n.zb.u16(), n.cop, parts, batch, n.in_h,
                                        n.in_w, n.cip, n.cop, stream_));
@@ -1293,7 +1304,8 @@ class Net {
               UNET_CALL(unet_tconv2x2_dgrad_bnred_bf16(dz, n.cop, n.w_bwd.u16(), p.gb.u16(), p.cop, p.zb.u16(), p.cop,
                                                        p.coef.f32(), p.bwd_partials.f32(), batch, n.in_h, n.in_w, n.cip,
                                                        n.cop, stream_));
-            p.bwd_partials_n = batch * unet_conv3x3_stat_tiles(n.in_h, n.in_w);
+            p.bwd_partials_n = n.type == CONV_LAYER ? conv_stat_rows(batch, n.in_h, n.in_w, n.cop, n.cip)
+                                                    : batch * unet_conv3x3_stat_tiles(n.in_h, n.in_w);
           } else if (n.type == CONV_LAYER && p.type == CONCAT_LAYER && !p.g_written && concat_second_is_fusable(p)) {
             // Input = concat(skip, up): the second half of the gradient is all the gradient the
             // upsampling layer's BN + ReLU output receives, so its pixel reduction is fused here too.
@@ -1301,7 +1313,7 @@ class Net {
             UNET_CALL(unet_conv3x3_dgrad_bnred_bf16(dz, n.cop, n.w_bwd.u16(), p.gb.u16(), p.cop, u.zb.u16(), u.cop,
                                                     u.coef.f32(), u.bwd_partials.f32(), p.c1, batch, n.in_h, n.in_w,
                                                     n.cop, n.cip, stream_));
-            u.bwd_partials_n = batch * unet_conv3x3_stat_tiles(n.in_h, n.in_w);
+            u.bwd_partials_n = conv_stat_rows(batch, n.in_h, n.in_w, n.cop, n.cip);
           } else if (n.type == CONV_LAYER) {
             UNET_CALL(unet_conv3x3_bf16(dz, n.cop, n.w_bwd.u16(), nullptr, 0, p.gb.u16(), p.cop, nullptr, batch, n.in_h,
                                         n.in_w, n.cop, n.cip, p.g_written ? 1 : 0, stream_));
