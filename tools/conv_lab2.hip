@@ -87,10 +87,25 @@ int main(int argc, char **argv) {
     for (int i = 0; i < 4096; ++i) hb[i] = 0.01f * (i % 17 - 8);
     CK(hipMemcpy(d_bias, hb.data(), 4096 * 4, hipMemcpyHostToDevice));
   }
+  float *d_bcf;
+  CK(hipMalloc(&d_bcf, 4096 * 16));
+  {
+    std::vector<float> hb(4096 * 4);
+    for (int i = 0; i < 4096; ++i) { hb[4 * i] = 1.0f + 0.01f * (i % 7); hb[4 * i + 1] = 0.001f * (i % 5 - 2); hb[4 * i + 2] = 0.002f * (i % 3); hb[4 * i + 3] = 1.1f; }
+    CK(hipMemcpy(d_bcf, hb.data(), 4096 * 16, hipMemcpyHostToDevice));
+  }
   const size_t stat_floats = (size_t)N * 2048 * 1024 * 2;
   CK(hipMalloc(&d_stats, stat_floats * 4));
   CK(hipMalloc(&d_stats_ref, stat_floats * 4));
   CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&pipe::conv3x3_pipe_kernel<false, pipe::EPI_STATS>),
+                         hipFuncAttributeMaxDynamicSharedMemorySize, pipe::LDS_BYTES));
+  CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&pipe::conv3x3_pipe_kernel<true, pipe::EPI_BRED>),
+                         hipFuncAttributeMaxDynamicSharedMemorySize, pipe::LDS_BYTES));
+  CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&pipe::conv3x3_pipe_kernel<false, pipe::EPI_BRED>),
+                         hipFuncAttributeMaxDynamicSharedMemorySize, pipe::LDS_BYTES));
+  CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&pipe::conv3x3_pipe_kernel<true, pipe::EPI_PLAIN>),
+                         hipFuncAttributeMaxDynamicSharedMemorySize, pipe::LDS_BYTES));
+  CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&pipe::conv3x3_pipe_kernel<false, pipe::EPI_PLAIN>),
                          hipFuncAttributeMaxDynamicSharedMemorySize, pipe::LDS_BYTES));
   CK(hipFuncSetAttribute(reinterpret_cast<const void *>(&pipe::conv3x3_pipe_kernel<true, pipe::EPI_STATS>),
                          hipFuncAttributeMaxDynamicSharedMemorySize, pipe::LDS_BYTES));
@@ -140,6 +155,25 @@ int main(int argc, char **argv) {
       unet_conv3x3_bf16(d_in, s.Ci, d_w, d_bias, s.Co, d_ref, s.Co, d_stats_ref, N, s.H, s.H, s.Ci, s.Co, 0, nullptr);
     }, 20);
     const float t_new = time_launch(launch, 20);
+    // the data-gradient variant with the fused batch-norm reduction (timing only; operands: z = the reference output)
+    pipe::Args b = a;
+    b.bias = nullptr; b.bz = d_ref; b.bz_ld = s.Co; b.bcf = reinterpret_cast<const float4 *>(d_bcf); b.bred_c0 = 0;
+    auto launch_bred = [&] {
+      if (ws)
+        hipLaunchKernelGGL((pipe::conv3x3_pipe_kernel<true, pipe::EPI_BRED>), dim3(grid), dim3(512), pipe::LDS_BYTES, 0, b);
+      else
+        hipLaunchKernelGGL((pipe::conv3x3_pipe_kernel<false, pipe::EPI_BRED>), dim3(grid), dim3(512), pipe::LDS_BYTES, 0, b);
+    };
+    pipe::Args c = a;
+    c.stats = nullptr;
+    auto launch_plain = [&] {
+      if (ws)
+        hipLaunchKernelGGL((pipe::conv3x3_pipe_kernel<true, pipe::EPI_PLAIN>), dim3(grid), dim3(512), pipe::LDS_BYTES, 0, c);
+      else
+        hipLaunchKernelGGL((pipe::conv3x3_pipe_kernel<false, pipe::EPI_PLAIN>), dim3(grid), dim3(512), pipe::LDS_BYTES, 0, c);
+    };
+    const float t_bred = time_launch(launch_bred, 20), t_plain = time_launch(launch_plain, 20);
+    printf("  [plain %6.1f us %5.0f TF | bred %6.1f us %5.0f TF] ", t_plain, flops / t_plain * 1e-6, t_bred, flops / t_bred * 1e-6);
     printf("%4dx%-4d %4d->%-4d %s grid %4d | library %6.1f us %5.0f TF | pipe %6.1f us %5.0f TF | mismatches %zu, stats rel %.2e\n",
            s.H, s.H, s.Ci, s.Co, ws ? "WS" : "  ", grid, t_lib, flops / t_lib * 1e-6, t_new, flops / t_new * 1e-6, bad, worst);
     fflush(stdout);

@@ -34,7 +34,8 @@ constexpr int W_INSTR = 9 * 64 * 4 / 64;           // 36
 constexpr int W_BYTES = W_INSTR * 1024;            // 36864: 9 taps x 64 channels x 64 B
 constexpr int STAGE_BYTES = HALO_BYTES + W_BYTES;  // 76800
 constexpr int MAX_WS_CHUNKS = 2;                   // weights resident in LDS up to C_in = 64
-constexpr int LDS_BYTES = 2 * STAGE_BYTES;         // 153600 (resident weights: 2 * HALO_BYTES + 2 * W_BYTES)
+constexpr int STAGES_BYTES = 2 * STAGE_BYTES;       // 153600 (resident weights: 2 * HALO_BYTES + 2 * W_BYTES)
+constexpr int LDS_BYTES = STAGES_BYTES + 64 * 16;  // + the batch-norm records of the 64 channels (EPI_BRED)
 
 struct Args {
   const bf16_t *in;
@@ -205,9 +206,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pipe_kernel(const Args a) {
 
   // ---- per-lane epilogue constants: the lane's 2 x 4 channels ----
   f32x4 biasv[2], scalev[2];
-  float4 bcf[BRED ? 8 : 1];
   const bool red_here = BRED && co0 >= a.bred_c0;  // uniform over the workgroup
   const int rc0 = co0 - a.bred_c0;
+  // BRED: the 64 channels' records {a, b, mean, 1/sqrt(var+eps)} wait in LDS and are read per tile epilogue;
+  // kept in registers across the MFMA loop they (with the prefetched z values) push the kernel into spills
+  float4 *lds_cf = reinterpret_cast<float4 *>(lds + STAGES_BYTES);
+  if (BRED && tid < 64) lds_cf[tid] = red_here ? a.bcf[rc0 + tid] : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
   for (int m = 0; m < 2; ++m) {
     const int ch = (cw * 2 + m) * 16 + 4 * kp;
@@ -222,7 +226,6 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pipe_kernel(const Args a) {
         scalev[m][j] = 1.f;
         biasv[m][j] = b;
       }
-      if (BRED) bcf[BRED ? m * 4 + j : 0] = red_here ? a.bcf[rc0 + ch + j] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   }
   const unsigned out_img_bytes = (unsigned)a.H * a.W * a.out_ld * 2u, z_img_bytes = (unsigned)a.H * a.W * a.bz_ld * 2u;
@@ -241,8 +244,25 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pipe_kernel(const Args a) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) ssum[m][j] = ssq[m][j] = 0.f;
 
+  const int ch16 = cw * 32 + (kp & 1) * 16 + (kp >> 1) * 8;  // first of the lane's 8 channels after the swap
   int s = 0;
   for (int it = 0; it < my_units; ++it) {
+    // this tile's output coordinates, and (BRED / ACC) the values its epilogue reads: requested before the
+    // last stage's MFMAs so that they have arrived when the epilogue starts
+    int n, y0, x0;
+    unit_coords(it, n, y0, x0);
+    const int x = x0 + l15;
+    const i64 img = (i64)n * a.H * a.W;
+    const auto ors = __builtin_amdgcn_make_buffer_rsrc(a.out + img * a.out_ld, 0, out_img_bytes, 0x00020000);
+    unsigned ooff[8];  // byte offset of the lane's 16 bytes in the output image, or OOB
+    bool okq[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int y = y0 + ph * 8 + q;
+      okq[q] = y < a.H && x < a.W;
+      ooff[q] = okq[q] ? (unsigned)(((y * a.W + x) * a.out_ld + co0 + ch16) * 2) : OOB;
+    }
+    i32x4 zq[BRED ? 8 : 1], oq[EPI == EPI_ACC ? 8 : 1];
     f32x4 acc[2][8];
 #pragma unroll
     for (int m = 0; m < 2; ++m)
@@ -261,6 +281,21 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pipe_kernel(const Args a) {
         const int it2 = (kc + 1 < nk) ? it : it + 1, kc2 = (kc + 1 < nk) ? kc + 1 : 0;
         if (!WS) issue_weights(kc2, weight_buf(s + 1, kc2));
         issue_halo(it2, kc2, halo_buf(s + 1));
+      }
+      if ((BRED || EPI == EPI_ACC) && kc == nk - 1) {
+        if (BRED) {  // the parent's pre-BN values (zeros for the channel half that takes no part)
+          const auto zrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(a.bz) + img * a.bz_ld, 0,
+                                                             red_here ? z_img_bytes : 0u, 0x00020000);
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            const int y = y0 + ph * 8 + q;
+            const unsigned zo = okq[q] ? (unsigned)(((y * a.W + x) * a.bz_ld + rc0 + ch16) * 2) : OOB;
+            zq[BRED ? q : 0] = __builtin_amdgcn_raw_buffer_load_b128(zrs, zo, 0, 0);
+          }
+        } else {
+#pragma unroll
+          for (int q = 0; q < 8; ++q) oq[EPI == EPI_ACC ? q : 0] = __builtin_amdgcn_raw_buffer_load_b128(ors, ooff[q], 0, 0);
+        }
       }
       const unsigned char *ldsX = halo_buf(s), *ldsW = weight_buf(s, kc);
 #pragma unroll
@@ -292,34 +327,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pipe_kernel(const Args a) {
     // vector-memory instructions per tile (epi_vmem_ops).  The matrix cores leave a lane with 4 channels of
     // each of its two 16-channel blocks; v_permlane16_swap between lanes 16 apart turns that into 8
     // consecutive channels of one block, so a lane moves 16 bytes and a pixel's 64 bytes leave in one piece.
-    int n, y0, x0;
-    unit_coords(it, n, y0, x0);
-    const int x = x0 + l15;
-    const i64 img = (i64)n * a.H * a.W;
-    const auto ors = __builtin_amdgcn_make_buffer_rsrc(a.out + img * a.out_ld, 0, out_img_bytes, 0x00020000);
-    const int ch16 = cw * 32 + (kp & 1) * 16 + (kp >> 1) * 8;  // first of the lane's 8 channels after the swap
-    unsigned ooff[8];  // byte offset of the lane's 16 bytes in the output image, or OOB
-    bool okq[8];
+    float4 bcf[BRED ? 8 : 1];
+    if (BRED) {
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int y = y0 + ph * 8 + q;
-      okq[q] = y < a.H && x < a.W;
-      ooff[q] = okq[q] ? (unsigned)(((y * a.W + x) * a.out_ld + co0 + ch16) * 2) : OOB;
-    }
-    i32x4 zq[BRED ? 8 : 1], oq[EPI == EPI_ACC ? 8 : 1];
-    if (BRED) {  // the parent's pre-BN values (zeros for the channel half that takes no part)
-      const auto zrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(a.bz) + img * a.bz_ld, 0,
-                                                         red_here ? z_img_bytes : 0u, 0x00020000);
+      for (int m = 0; m < 2; ++m)
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const int y = y0 + ph * 8 + q;
-        const unsigned zo = okq[q] ? (unsigned)(((y * a.W + x) * a.bz_ld + rc0 + ch16) * 2) : OOB;
-        zq[BRED ? q : 0] = __builtin_amdgcn_raw_buffer_load_b128(zrs, zo, 0, 0);
-      }
-    }
-    if (EPI == EPI_ACC) {
-#pragma unroll
-      for (int q = 0; q < 8; ++q) oq[EPI == EPI_ACC ? q : 0] = __builtin_amdgcn_raw_buffer_load_b128(ors, ooff[q], 0, 0);
+        for (int j = 0; j < 4; ++j) bcf[BRED ? m * 4 + j : 0] = lds_cf[(cw * 2 + m) * 16 + 4 * kp + j];
     }
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
@@ -382,7 +395,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pipe_kernel(const Args a) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         float sv = row_sum16(ssum[m][j]), qv = row_sum16(ssq[m][j]);
-        if (BRED) sv = (sv - bcf[BRED ? m * 4 + j : 0].z * qv) * bcf[BRED ? m * 4 + j : 0].w;
+        if (BRED) {
+          const float4 c = lds_cf[(cw * 2 + m) * 16 + 4 * kp + j];
+          sv = (sv - c.z * qv) * c.w;
+        }
         o[2 * j] = sv;
         o[2 * j + 1] = qv;
       }
