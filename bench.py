@@ -139,10 +139,15 @@ def main():
     ap.add_argument("--base", type=int, default=64, help="channels of the first stage (unet4 graph)")
     ap.add_argument("--graph", default=os.environ.get("UNET_BENCH_GRAPH", "unet4_base64"),
                     choices=["unet4_base64", "mainpy", "attention_unet"])
+    ap.add_argument("--infer", action="store_true",
+                    help="time the inference forward pass (BASELINE config 2 with --dtype fp32 --batch 1) instead of a train step")
+    ap.add_argument("--dtype", default=None, choices=["bf16", "fp32"], help="compute path (default: bf16 where the graph allows)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="skip the per-kernel event timing")
     args = ap.parse_args()
 
+    if args.dtype:
+        os.environ["UNET_DTYPE"] = args.dtype
     import torch
     import torch.distributed as dist
     import neural_net as nn
@@ -184,6 +189,12 @@ def main():
     trainer.broadcast_parameters()
     lr = 1e-3
 
+    def one_step():
+        if args.infer:
+            net.forward_device(images.data_ptr(), args.batch, True)
+        else:
+            trainer.train_step(images.data_ptr(), masks.data_ptr(), args.batch, lr)
+
     def sync():
         net.synchronize()
         torch.cuda.synchronize(device)
@@ -214,7 +225,7 @@ def main():
         them by the algorithmic figure of the layer table for the families the table covers."""
         alg = family_flops(graph, args.batch)
         for name, f in fams.items():
-            if name in alg and dtype == "bf16":
+            if name in alg and dtype == "bf16" and not args.infer:
                 f["flops"] = alg[name] * steps
         return fams
 
@@ -228,7 +239,7 @@ def main():
         return kernels
 
     for _ in range(args.warmup):
-        trainer.train_step(images.data_ptr(), masks.data_ptr(), args.batch, lr)
+        one_step()
     sync()
 
     # Untimed probe: every kernel family timed with HIP events (two event records per launch cost
@@ -239,7 +250,7 @@ def main():
     if probe_steps:
         capi.unet_prof_enable(1)
         for _ in range(probe_steps):
-            trainer.train_step(images.data_ptr(), masks.data_ptr(), args.batch, lr)
+            one_step()
         sync()
         probe = algorithmic(read_families(), probe_steps)
         dominant_mask = max(group_kernels(probe).values(), key=lambda k: k["ms"])["mask"]
@@ -248,7 +259,7 @@ def main():
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        trainer.train_step(images.data_ptr(), masks.data_ptr(), args.batch, lr)
+        one_step()
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -262,7 +273,7 @@ def main():
         capi.unet_prof_enable(0)
 
     loss = None
-    if rank == 0:
+    if rank == 0 and not args.infer:
         lv = torch.zeros(3 * args.batch, device=device)
         capi.unet_memcpy_d2d(lv.data_ptr(), net.loss_values_ptr(), 12 * args.batch, None)
         torch.cuda.synchronize(device)
@@ -279,16 +290,19 @@ def main():
     value = args.batch * world * args.steps / elapsed
     fwd_flops, step_flops = conv_flops(graph, args.batch)
     out = {
-        "metric": f"U-Net train images/s (fwd+bwd, {H}x{W}, {dtype})",
+        "metric": (f"U-Net inference images/s (fwd, {H}x{W}, {dtype})" if args.infer
+                   else f"U-Net train images/s (fwd+bwd, {H}x{W}, {dtype})"),
         "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
-        "config": {"workload": f"{args.graph if args.base == 64 else 'unet4_base%d' % args.base} train step (fwd+bwd+Adam, BatchNorm, Dice loss), "
+        "config": {"workload": f"{args.graph if args.base == 64 else 'unet4_base%d' % args.base} "
+                               f"{'inference forward (BatchNorm with running statistics)' if args.infer else 'train step (fwd+bwd+Adam, BatchNorm, Dice loss)'}, "
                                f"batch {args.batch}x3x{H}x{W} per GPU",
                    "global_batch": args.batch * world, "parallelism": f"dp{world}",
-                   "parameters": int(net.num_parameters()), "conv_tflop_per_step": round(step_flops / 1e12, 3)},
+                   "parameters": int(net.num_parameters()),
+                   "conv_tflop_per_step": round((fwd_flops if args.infer else step_flops) / 1e12, 4)},
         "hbm_in_use_gb": round((free0 - free1) / 1e9, 2),
-        "step_tflops": round(step_flops * world / elapsed * args.steps / 1e12, 2),
+        "step_tflops": round((fwd_flops if args.infer else step_flops) * world / elapsed * args.steps / 1e12, 2),
         "final_loss": loss,
     }
     if families:
@@ -332,7 +346,7 @@ def main():
                 "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["flops"] else None,
                 "gbs": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["bytes"] else None}
             for k, v in sorted(probe.items(), key=lambda kv: -kv[1]["ms"])}
-    if world == 1 and not args.no_cpu_baseline:
+    if world == 1 and not args.no_cpu_baseline and not args.infer:
         dt, sample_flops = cpu_baseline_port()
         img_flops = step_flops / args.batch
         out["cpu_baseline"] = {

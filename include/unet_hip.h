@@ -397,6 +397,11 @@ int unet_conv3x3_bf16(const uint16_t *in, int in_ld, const uint16_t *w_packed, c
                       uint16_t *out, int out_ld, float *stat_partials, int N, int H, int W, int CiP, int CoP,
                       int accumulate, unet_stream_t stream);
 int unet_conv3x3_stat_rows(int N, int H, int W, int CiP, int CoP);
+/* Two kernels serve the 3x3 entry points with bit-identical outputs: a persistent pipelined one (images of 32
+ * rows and more, 64-channel blocks) and a general one.  The pipelined kernel is used when a call has at least
+ * this many (32x16 pixel tile, 64-channel block) work units (default 256: one per CU).  Sets the threshold when
+ * min_units >= 0; returns the previous value.  Process-wide; meant for tests and tuning. */
+int unet_conv3x3_pipeline_min_units(int min_units);
 int unet_conv3x3_stat_tiles(int H, int W);
 /* Inference: the same convolution with the batch norm (running statistics) and ReLU that follow it folded into the
  * epilogue (cudaConvolve + cudaBatchNormInference + cudaRelu in one kernel): out = relu(a*(conv + bias) + b) with

@@ -282,7 +282,7 @@ def _ulp_nudge(z, gen):
     return z + (moved.to(z.dtype) - z.detach())
 
 
-def forward(graph, params, x, training=True, running=None, emulate_bf16=False, nudge_seed=None):
+def forward(graph, params, x, training=True, running=None, emulate_bf16=False, nudge_seed=None, round_fp32=False):
     """x float64 [N,C,H,W] -> list of per-layer activations.  `running`
     (optional list of [mean,var] interleaved arrays per layer) is used when
     training=False.
@@ -300,6 +300,8 @@ def forward(graph, params, x, training=True, running=None, emulate_bf16=False, n
     rounded -- a second, equally valid evaluation of the same network, used to measure how far two correct
     bf16 runs drift apart (tools/bf16_grad_sensitivity.py)."""
     gen = None if nudge_seed is None else torch.Generator().manual_seed(int(nudge_seed))
+    if round_fp32:   # every convolution output rounded to fp32 (what an fp32 engine stores), values only
+        rnd = lambda t: t + (t.detach().to(torch.float32).to(t.dtype) - t.detach())
     rnd = _RoundBF16.apply if emulate_bf16 else (lambda t: t)
     rndw = _RoundBF16Value.apply if emulate_bf16 else (lambda t: t)
     if emulate_bf16:

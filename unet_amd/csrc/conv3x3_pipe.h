@@ -422,7 +422,17 @@ inline int plan_grid(int N, int H, int W, int CoP, int max_wgs = 256) {
 // Rows of partial sums the kernel writes (in all, not per image): four per workgroup of a channel block.
 inline int stat_rows(int N, int H, int W, int CoP, int max_wgs = 256) { return 4 * (plan_grid(N, H, W, CoP, max_wgs) / (CoP / 64)); }
 
-// Whether the pipelined kernel serves this shape (the choice must not depend on the batch size).
-inline bool eligible(int H, int W, int CiP, int CoP) { return H >= 32 && W >= 16 && CoP % 64 == 0 && CiP % 32 == 0; }
+// Whether the pipelined kernel serves this call.  It needs images of 32 rows and more, 64-channel output
+// blocks, and enough (tile, channel block) units to give every CU a workgroup: below that (single images at
+// inference, the deepest levels) the general kernel's smaller workgroups spread the work better.  The two
+// kernels return bit-identical outputs, so the choice may depend on the batch size.
+inline int &min_units() {
+  static int v = 256;
+  return v;
+}
+inline bool eligible(int N, int H, int W, int CiP, int CoP) {
+  if (!(H >= 32 && W >= 16 && CoP % 64 == 0 && CiP % 32 == 0)) return false;
+  return (i64)N * ((H + TH - 1) / TH) * ((W + TW - 1) / TW) * (CoP / 64) >= min_units();
+}
 
 }  // namespace pipe

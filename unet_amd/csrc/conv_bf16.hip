@@ -450,7 +450,7 @@ int launch_conv(const ConvArgs &a, hipStream_t s) {
 int launch_pipe_from(const ConvArgs &c, hipStream_t s);
 
 int launch_conv_any(int taps, const ConvArgs &a, hipStream_t s) {
-  if (taps == 9 && pipe::eligible(a.Ho, a.Wo, a.Ci, a.CoP) && !(a.accumulate && a.stats)) return launch_pipe_from(a, s);
+  if (taps == 9 && pipe::eligible(a.N, a.Ho, a.Wo, a.Ci, a.CoP) && !(a.accumulate && a.stats)) return launch_pipe_from(a, s);
   const bool wide = a.CoP % 64 == 0, deep = a.Ci % 64 == 0;
   // the 16x16x32 path for all but the smallest images (at batch 16: wherever a launch has more than one workgroup
   // per CU).  The choice must not depend on the batch size: the two loops add in different orders, and inference
@@ -474,8 +474,8 @@ int launch_conv_any(int taps, const ConvArgs &a, hipStream_t s) {
 }
 
 // The pipelined persistent kernel (conv3x3_pipe.h) for the shapes it serves; returns false when the shape
-// stays with conv_mfma_kernel.  Which kernel runs depends on the image and channel sizes only, never on the
-// batch (both add in the same order anyway: their outputs are bit-identical).
+// stays with conv_mfma_kernel.  Both add in the same order: their outputs are bit-identical, so one image gives
+// the same result alone (general kernel) and inside a batch (pipelined kernel).
 template <bool WS, int EPI>
 int launch_pipe(const pipe::Args &a, int grid, hipStream_t s) {
   static bool attr_set[64] = {};
@@ -775,9 +775,15 @@ int unet_conv3x3_bn_relu_bf16(const uint16_t *in, int in_ld, const uint16_t *w_p
 
 int unet_conv3x3_stat_tiles(int H, int W) { return ((H + 15) / 16) * ((W + 15) / 16); }
 
+int unet_conv3x3_pipeline_min_units(int min_units) {
+  const int old = pipe::min_units();
+  if (min_units >= 0) pipe::min_units() = min_units;
+  return old;
+}
+
 int unet_conv3x3_stat_rows(int N, int H, int W, int CiP, int CoP) {
   if (CiP < 32) CiP = 32;
-  if (pipe::eligible(H, W, CiP, CoP)) return pipe::stat_rows(N, H, W, CoP);
+  if (pipe::eligible(N, H, W, CiP, CoP)) return pipe::stat_rows(N, H, W, CoP);
   return N * unet_conv3x3_stat_tiles(H, W);
 }
 

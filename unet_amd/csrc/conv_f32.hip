@@ -83,6 +83,110 @@ __global__ __launch_bounds__(256) void conv_fwd_f32_kernel(
   }
 }
 
+// ------------------------------------------------- forward on the matrix cores --
+// 3x3 / pad 1 / stride 1 as an implicit GEMM on v_mfma_f32_32x32x2_f32 (fp32 in, fp32 accumulate: every
+// product and sum is an exact fp32 fma, like the vector kernel above, at the matrix pipe's rate):
+//   D[co][pixel] += W[co][(ci, tap)] * X[(ci, tap)][pixel],  K = (input channel, filter tap), two K per MFMA.
+// A workgroup (4 waves) owns 256 output pixels of one image x (32 MB) output channels; a wave owns two
+// 32-pixel blocks (TW = 32: two tile rows of 32 pixels; TW = 16: four tile rows of 16) and MB 32-channel
+// blocks.  Input channels go through LDS eight at a time: the halo patch [ci][rows + 2][pitch] and the weight
+// slice [ci][tap][co].  Operand fragments are single floats per lane: lane l holds K index l / 32 and
+// row / column l % 32, so a fragment read is 32 consecutive floats per K index (the patch pitch puts the
+// second pixel row of a TW = 16 block on the other half of the banks).
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+constexpr int M_CIB = 8;
+
+template <int TW, int MB>
+__global__ __launch_bounds__(256) void conv3x3_fwd_mfma_f32_kernel(const float *__restrict__ Wt,
+                                                                   const float *__restrict__ X,
+                                                                   float *__restrict__ Y, int Ci, int Co, int H,
+                                                                   int W, int tilesW, int splits, int ci_per_split) {
+  constexpr int TH = 256 / TW;                  // tile rows
+  constexpr int PR = TH + 2, PC = TW + 2;       // patch rows / columns
+  constexpr int PITCH = TW == 32 ? 36 : 48;     // floats; 48 = 16 mod 32
+  constexpr int COB = 32 * MB;
+  constexpr int RPB = 32 / TW;                  // tile rows per 32-pixel block
+  __shared__ float patch[M_CIB][PR][PITCH];
+  __shared__ float wts[M_CIB][9][COB];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int th0 = (blockIdx.x / tilesW) * TH, tw0 = (blockIdx.x % tilesW) * TW;
+  const int co0 = blockIdx.y * COB;
+  // splits > 1: blockIdx.z = image * splits + split; a split covers ci_per_split input channels and writes its
+  // partial sums (no bias) to Y[split][image][...], which conv_split_reduce_f32_kernel adds up in a fixed order
+  const int split = blockIdx.z % splits;
+  const i64 n = blockIdx.z / splits, n_out = (i64)split * (gridDim.z / splits) + n;
+  const int ci_begin = split * ci_per_split, ci_end = min(Ci, ci_begin + ci_per_split);
+  const int kl = lane >> 5, l32 = lane & 31;
+  const int brow = l32 / TW, bcol = l32 % TW;   // pixel of this lane inside a 32-pixel block
+  f32x16_t acc[MB][2];
+#pragma unroll
+  for (int m = 0; m < MB; ++m)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][b][r] = 0.f;
+
+  for (int ci0 = ci_begin; ci0 < ci_end; ci0 += M_CIB) {
+    __syncthreads();
+    for (int e = tid; e < M_CIB * PR * PC; e += 256) {
+      const int ci = e / (PR * PC), r = e - ci * PR * PC, ph = r / PC, pw = r - ph * PC;
+      const int ih = th0 - 1 + ph, iw = tw0 - 1 + pw;
+      float v = 0.f;
+      if (ci0 + ci < ci_end && ih >= 0 && ih < H && iw >= 0 && iw < W) v = X[((n * Ci + ci0 + ci) * H + ih) * W + iw];
+      patch[ci][ph][pw] = v;
+    }
+    for (int e = tid; e < M_CIB * COB * 9; e += 256) {  // global order (ci, co, tap): contiguous runs of COB * 9 floats
+      const int ci = e / (COB * 9), r = e - ci * COB * 9, co = r / 9, t = r - co * 9;
+      float v = 0.f;
+      if (ci0 + ci < ci_end && co0 + co < Co) v = Wt[((i64)(ci0 + ci) * Co + co0) * 9 + r];
+      wts[ci][t][co] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int pair = 0; pair < M_CIB / 2; ++pair) {
+      const int ci = 2 * pair + kl;
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const int kh = tap / 3, kw = tap % 3;
+        float af[MB], bf[2];
+#pragma unroll
+        for (int m = 0; m < MB; ++m) af[m] = wts[ci][tap][m * 32 + l32];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) bf[b] = patch[ci][(2 * wave + b) * RPB + brow + kh][bcol + kw];
+#pragma unroll
+        for (int m = 0; m < MB; ++m)
+#pragma unroll
+          for (int b = 0; b < 2; ++b) acc[m][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[m], bf[b], acc[m][b], 0, 0, 0);
+      }
+    }
+  }
+  const float *bias = Wt + (i64)Ci * Co * 9;
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    const int y = th0 + (2 * wave + b) * RPB + brow, x = tw0 + bcol;
+    if (y >= H || x >= W) continue;
+#pragma unroll
+    for (int m = 0; m < MB; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {  // register r of a 32x32 block holds row (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+        const int co = co0 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * kl;
+        if (co < Co) Y[((n_out * Co + co) * H + y) * W + x] = acc[m][b][r] + (splits > 1 ? 0.f : bias[co]);
+      }
+  }
+}
+
+// Y[i] = bias[channel of i] + sum over splits (ascending) of partial[split][i]
+__global__ __launch_bounds__(256) void conv_split_reduce_f32_kernel(const float *__restrict__ partial,
+                                                                    const float *__restrict__ bias,
+                                                                    float *__restrict__ Y, i64 total, i64 HW, int Co,
+                                                                    int splits) {
+  for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (i64)gridDim.x * blockDim.x) {
+    float s = bias[(i / HW) % Co];
+    for (int k = 0; k < splits; ++k) s += partial[k * total + i];
+    Y[i] = s;
+  }
+}
+
 // ---------------------------------------------------------- backward data --
 // dX[n,ci,hi,wi] = sum_co sum_kh,kw W[ci,co,kh,kw] * dY[n,co,(hi+p-kh)/s,(wi+p-kw)/s]
 // over taps where the division is exact and the result is in range
@@ -404,10 +508,54 @@ int unet_convolve_f32(const float *weights, const float *inputs, float *activati
   if (lds > kMaxDynLds)
     return unet_set_error(UNET_ERR_UNSUPPORTED, "unet_convolve_f32: kernel %d / stride %d needs %zu B of LDS", k,
                           stride, lds);
-  const int tilesH = (Ho + TILE - 1) / TILE, tilesW = (Wo + TILE - 1) / TILE;
-  dim3 grid((unsigned)(tilesH * tilesW), (unsigned)((Co + F_COB - 1) / F_COB), (unsigned)N);
   const double flops = 2.0 * N * Co * Ho * Wo * (double)Ci * k * k;
   ProfScope prof(PROF_CONV_FWD_F32, flops, 4.0 * ((double)N * Ci * Hi * Wi + (double)N * Co * Ho * Wo), as_stream(s));
+  if (k == 3 && pad == 1 && stride == 1 && Co >= 16 && Wo >= 8 && Ho >= 4) {
+    // matrix-core kernel: 8 x 32 pixel tiles for wide images, 16 x 16 otherwise; 64 output channels per
+    // workgroup, 32 when that is needed to give every CU a workgroup
+    const bool wide = Wo >= 32;
+    const int tW = wide ? (Wo + 31) / 32 : (Wo + 15) / 16, tH = wide ? (Ho + 7) / 8 : (Ho + 15) / 16;
+    const bool two = Co > 32 && (i64)tW * tH * N * ((Co + 63) / 64) >= 256;
+    const int cob = two ? (Co + 63) / 64 : (Co + 31) / 32;
+    // few workgroups (single images, deep levels): the input channels are split over more workgroups, each
+    // writing partial sums that a second kernel adds in a fixed order
+    int splits = 1;
+    const i64 wgs = (i64)tW * tH * N * cob;
+    if (wgs < 192) {
+      splits = (int)((384 + wgs - 1) / wgs);
+      const int max_splits = Ci / 32 > 0 ? Ci / 32 : 1;
+      if (splits > max_splits) splits = max_splits;
+      if (splits > 16) splits = 16;
+    }
+    int ci_per_split = ((Ci + splits - 1) / splits + M_CIB - 1) / M_CIB * M_CIB;
+    splits = (Ci + ci_per_split - 1) / ci_per_split;
+    float *dst = activations;
+    const i64 total = (i64)N * Co * Ho * Wo;
+    if (splits > 1) {
+      void *ws;
+      int rc = unet_workspace(&ws, sizeof(float) * (size_t)splits * (size_t)total, as_stream(s));
+      if (rc) return rc;
+      dst = (float *)ws;
+    }
+    dim3 g((unsigned)(tW * tH), (unsigned)cob, (unsigned)(N * splits));
+    if (wide && two)
+      hipLaunchKernelGGL((conv3x3_fwd_mfma_f32_kernel<32, 2>), g, dim3(256), 0, as_stream(s), weights, inputs, dst, Ci, Co, Ho, Wo, tW, splits, ci_per_split);
+    else if (wide)
+      hipLaunchKernelGGL((conv3x3_fwd_mfma_f32_kernel<32, 1>), g, dim3(256), 0, as_stream(s), weights, inputs, dst, Ci, Co, Ho, Wo, tW, splits, ci_per_split);
+    else if (two)
+      hipLaunchKernelGGL((conv3x3_fwd_mfma_f32_kernel<16, 2>), g, dim3(256), 0, as_stream(s), weights, inputs, dst, Ci, Co, Ho, Wo, tW, splits, ci_per_split);
+    else
+      hipLaunchKernelGGL((conv3x3_fwd_mfma_f32_kernel<16, 1>), g, dim3(256), 0, as_stream(s), weights, inputs, dst, Ci, Co, Ho, Wo, tW, splits, ci_per_split);
+    UNET_LAUNCH_CHECK("conv3x3_fwd_mfma_f32_kernel");
+    if (splits > 1) {
+      hipLaunchKernelGGL(conv_split_reduce_f32_kernel, dim3(ew_grid(total)), dim3(256), 0, as_stream(s), (const float *)dst,
+                         weights + (i64)Ci * Co * 9, activations, total, (i64)Ho * Wo, Co, splits);
+      UNET_LAUNCH_CHECK("conv_split_reduce_f32_kernel");
+    }
+    return UNET_OK;
+  }
+  const int tilesH = (Ho + TILE - 1) / TILE, tilesW = (Wo + TILE - 1) / TILE;
+  dim3 grid((unsigned)(tilesH * tilesW), (unsigned)((Co + F_COB - 1) / F_COB), (unsigned)N);
   if (k == 3)
     hipLaunchKernelGGL(conv_fwd_f32_kernel<3>, grid, dim3(256), lds, as_stream(s), weights, inputs, activations,
                        Ci, Co, Ho, Wo, Hi, Wi, pad, stride, k, tilesW);
