@@ -173,6 +173,17 @@ int unet_sigmoid_f32(const float *inputs, float *activations, int64_t num_activa
 /* activations = the sigmoid OUTPUT. */
 int unet_sigmoid_backward_f32(const float *grad_activations, const float *activations,
                               float *grad_inputs, int64_t num_activations, unet_stream_t stream);
+/* LEAKY_ReLU and TANH of enum Activation_type (layer.h:31), which the reference declares (LayerDesc carries
+ * leaky_const, layer.h:36-44) but runs as ReLU (convolution_layer_functions.h:59-65): y = x > 0 ? x : slope*x
+ * with the backward on the PRE-activation values like cudaReluBackward; y = tanh(x) with the backward on the
+ * OUTPUT like cudaSigmoidBackward, dx = dy*(1 - y^2). */
+int unet_leaky_relu_f32(const float *inputs, float *activations, int64_t num_activations, float slope,
+                        unet_stream_t stream);
+int unet_leaky_relu_backward_f32(const float *grad_activations, const float *inputs, float *grad_inputs,
+                                 int64_t num_activations, float slope, unet_stream_t stream);
+int unet_tanh_f32(const float *inputs, float *activations, int64_t num_activations, unet_stream_t stream);
+int unet_tanh_backward_f32(const float *grad_activations, const float *activations, float *grad_inputs,
+                           int64_t num_activations, unet_stream_t stream);
 
 /* ---- max pool (cuda_lib.h:69-77, 202-211) -------------------------------- */
 
@@ -269,12 +280,27 @@ int unet_concat_f32(const float *activations_1, const float *activations_2, floa
 int unet_concat_backward_f32(const float *dLdY, float *dLdX, int H, int W, int C1, int C2,
                              int batch_size, unet_stream_t stream);
 
+/* cudaConcat for a first tensor that is LARGER than the second (skip connections of U-Nets built from
+ * unpadded convolutions, which the reference's CONV descriptor allows but its concat rejects, layer.h:523-533):
+ * A [N,C1,Ha,Wa] is centre-cropped to [Hb,Wb] (offsets (Ha-Hb)/2, (Wa-Wb)/2), then out[n,0:C1] = crop(A[n]),
+ * out[n,C1:C1+C2] = B[n].  Backward: dA (full size, zero outside the window) and dB. */
+int unet_concat_crop_f32(const float *activations_1, const float *activations_2, float *activations, int batch_size,
+                         int C1, int C2, int H1, int W1, int H2, int W2, unet_stream_t stream);
+int unet_concat_crop_backward_f32(const float *dLdY, float *dA, float *dB, int batch_size, int C1, int C2, int H1,
+                                  int W1, int H2, int W2, unet_stream_t stream);
+
 /* ---- losses (cuda_lib.h:32-36, 134-149) ---------------------------------- */
 
 /* The kernel half of cudaDiceScore: loss_values[3n..3n+2] = [sum m*p, sum m,
  * sum p] per sample (deterministic; the reference uses float atomics). */
 int unet_dice_sums_f32(const float *mask, const float *prediction, int H, int W, int batch_size,
                        float *loss_values, unet_stream_t stream);
+/* The forward value of the difference loss, which the reference never computes (its train() prints the Dice
+ * figures whatever the loss, neural_net.h:136-185): loss_values[3n..3n+2] = [sum (p-m)^2, sum m, sum p] per
+ * sample; the loss is 0.5 * sum_n loss_values[3n] / (N*H*W), the function whose gradient
+ * unet_difference_loss_backward_f32 returns. */
+int unet_difference_loss_sums_f32(const float *mask, const float *prediction, int H, int W, int batch_size,
+                                  float *loss_values, unet_stream_t stream);
 /* Replaces cudaDiceScore: unet_dice_sums_f32, then copies the sums to the
  * host (synchronises `stream`) and returns mean_n 2*I/(sum m + sum p + 1e-5)
  * in *dice_host. */

@@ -210,6 +210,49 @@ def sigmoid_backward(dy, y):
     return _ew(lib().oracle_sigmoid_backward, dy, y)
 
 
+def leaky_relu(x, slope):
+    x = _c(x)
+    out = np.empty_like(x)
+    lib().oracle_leaky_relu(_p(x), _p(out), _L(out.size), ctypes.c_float(slope))
+    return out
+
+
+def leaky_relu_backward(dy, x, slope):
+    dy, x = _c(dy), _c(x)
+    out = np.empty_like(x)
+    lib().oracle_leaky_relu_backward(_p(dy), _p(x), _p(out), _L(out.size), ctypes.c_float(slope))
+    return out
+
+
+def tanh(x):
+    return _ew(lib().oracle_tanh, x)
+
+
+def tanh_backward(dy, y):
+    return _ew(lib().oracle_tanh_backward, dy, y)
+
+
+def concat_crop(a, b):
+    """a [N,C1,Ha,Wa] centre-cropped to b's [Hb,Wb], then concatenated with b along the channels."""
+    a, b = _c(a), _c(b)
+    n, c1, ha, wa = a.shape
+    _, c2, hb, wb = b.shape
+    out = np.empty((n, c1 + c2, hb, wb), np.float32)
+    lib().oracle_concat_crop(_p(a), _p(b), _p(out), _I(n), _I(c1), _I(c2), _I(ha), _I(wa), _I(hb), _I(wb))
+    return out
+
+
+def concat_crop_backward(dy, c1, ha, wa):
+    """-> (dA [N,C1,Ha,Wa] zero outside the cropped window, dB [N,C2,Hb,Wb])."""
+    dy = _c(dy)
+    n, c, hb, wb = dy.shape
+    c2 = c - c1
+    da = np.empty((n, c1, ha, wa), np.float32)
+    db = np.empty((n, c2, hb, wb), np.float32)
+    lib().oracle_concat_crop_backward(_p(dy), _p(da), _p(db), _I(n), _I(c1), _I(c2), _I(ha), _I(wa), _I(hb), _I(wb))
+    return da, db
+
+
 def dice_score(mask, pred):
     """mask, pred [N,H,W] -> (mean dice, loss_values[3N])."""
     mask, pred = _c(mask), _c(pred)

@@ -372,6 +372,37 @@ void oracle_concat_backward(const float *dy, float *da, float *db, int batch,
 
 /* ----------------------------------------------------------- activations -- */
 
+/* Concat of a skip tensor that is LARGER than the tensor from below (U-Nets built from unpadded
+ * convolutions): A [N,C1,Ha,Wa] is centre-cropped to B's [Hb,Wb] (offsets (Ha-Hb)/2, (Wa-Wb)/2) and laid out
+ * like cudaConcat (cuda_ops.cu:64-91): out[n,0:C1] = crop(A[n]), out[n,C1:] = B[n].  The reference rejects
+ * unequal sizes (layer.h:523-533); this is the extension that makes its valid-convolution descriptors usable.
+ * Backward: dA is zero outside the window. */
+void oracle_concat_crop(const float *a, const float *b, float *out, int N, int C1, int C2, int Ha, int Wa, int Hb,
+                        int Wb) {
+  const int oy = (Ha - Hb) / 2, ox = (Wa - Wb) / 2;
+  for (i64 n = 0; n < N; ++n) {
+    for (i64 c = 0; c < C1; ++c)
+      for (i64 y = 0; y < Hb; ++y)
+        for (i64 x = 0; x < Wb; ++x)
+          out[((n * (C1 + C2) + c) * Hb + y) * Wb + x] = a[((n * C1 + c) * Ha + y + oy) * Wa + x + ox];
+    for (i64 c = 0; c < C2; ++c)
+      for (i64 i = 0; i < (i64)Hb * Wb; ++i) out[(n * (C1 + C2) + C1 + c) * Hb * Wb + i] = b[(n * C2 + c) * Hb * Wb + i];
+  }
+}
+void oracle_concat_crop_backward(const float *dy, float *da, float *db, int N, int C1, int C2, int Ha, int Wa,
+                                 int Hb, int Wb) {
+  const int oy = (Ha - Hb) / 2, ox = (Wa - Wb) / 2;
+  for (i64 i = 0; i < (i64)N * C1 * Ha * Wa; ++i) da[i] = 0.f;
+  for (i64 n = 0; n < N; ++n) {
+    for (i64 c = 0; c < C1; ++c)
+      for (i64 y = 0; y < Hb; ++y)
+        for (i64 x = 0; x < Wb; ++x)
+          da[((n * C1 + c) * Ha + y + oy) * Wa + x + ox] = dy[((n * (C1 + C2) + c) * Hb + y) * Wb + x];
+    for (i64 c = 0; c < C2; ++c)
+      for (i64 i = 0; i < (i64)Hb * Wb; ++i) db[(n * C2 + c) * Hb * Wb + i] = dy[(n * (C1 + C2) + C1 + c) * Hb * Wb + i];
+  }
+}
+
 /* reluKernel / reluBackwardKernel, cuda_ops.cu:93-123, 188-221.  Backward
  * masks on the PRE-activation input. */
 void oracle_relu(const float *x, float *y, i64 n) {
@@ -380,6 +411,22 @@ void oracle_relu(const float *x, float *y, i64 n) {
 void oracle_relu_backward(const float *dy, const float *x, float *dx, i64 n) {
   for (i64 i = 0; i < n; ++i) dx[i] = x[i] > 0.0f ? dy[i] : 0.0f;
 }
+/* LEAKY_ReLU / TANH of enum Activation_type (layer.h:31): declared by the reference, run there as ReLU
+ * (convolution_layer_functions.h:59-65); restated from their definitions.  The leaky backward masks on the
+ * pre-activation like reluBackwardKernel, the tanh backward uses the output like sigmoidBackwardKernel. */
+void oracle_leaky_relu(const float *x, float *y, i64 n, float slope) {
+  for (i64 i = 0; i < n; ++i) y[i] = x[i] > 0.f ? x[i] : slope * x[i];
+}
+void oracle_leaky_relu_backward(const float *dy, const float *x, float *dx, i64 n, float slope) {
+  for (i64 i = 0; i < n; ++i) dx[i] = x[i] > 0.f ? dy[i] : slope * dy[i];
+}
+void oracle_tanh(const float *x, float *y, i64 n) {
+  for (i64 i = 0; i < n; ++i) y[i] = (float)tanh((double)x[i]);
+}
+void oracle_tanh_backward(const float *dy, const float *y, float *dx, i64 n) {
+  for (i64 i = 0; i < n; ++i) dx[i] = (float)((double)dy[i] * (1.0 - (double)y[i] * (double)y[i]));
+}
+
 /* sigmoidKernel / sigmoidBackwardKernel, cuda_ops.cu:125-186 and
  * cuda_lib.h:22-24.  Backward takes the OUTPUT y. */
 void oracle_sigmoid(const float *x, float *y, i64 n) {

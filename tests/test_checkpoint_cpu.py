@@ -64,3 +64,60 @@ def test_attention_gate_parameters_round_trip_and_match_torch(oracle):
     np.testing.assert_allclose(a.numpy(), alpha, rtol=1e-5, atol=1e-6)
     with np.testing.assert_raises(RuntimeError):
         checkpoint.attention_to_torch(flat[:-1], cx, cg)
+
+
+class _FakeNet:
+    """The slice of neural_net.NeuralNet that save()/load() use, on host arrays."""
+
+    def __init__(self, seed):
+        rng = np.random.default_rng(seed)
+        self.layout = [(0, 0, 6, 4), (2, 10, 4, 6)]
+        self.params = rng.standard_normal(20).astype(np.float32)
+        self.running = {0: rng.standard_normal(4).astype(np.float32), 2: rng.standard_normal(6).astype(np.float32)}
+        self.adam = rng.standard_normal(40).astype(np.float32)
+        self.steps = 7
+        self.writes = 0
+
+    def parameter_layout(self): return self.layout
+    def num_parameters(self): return self.params.size
+    def get_parameters(self): return self.params.copy()
+    def running_stats(self, i): return self.running[i].copy()
+    def get_optimizer_state(self): return self.adam.copy()
+    def optimizer_steps(self): return self.steps
+
+    def set_parameters(self, p):
+        self.writes += 1
+        self.params = np.array(p)
+
+    def set_running_stats(self, i, r):
+        self.writes += 1
+        self.running[i] = np.array(r)
+
+    def set_optimizer_state(self, a, steps):
+        self.writes += 1
+        self.adam, self.steps = np.array(a), steps
+
+
+def test_save_load_agree_on_the_file_name_and_validate_before_writing(tmp_path):
+    import pytest
+    a, b = _FakeNet(1), _FakeNet(2)
+    for name in ("ckpt", "ckpt2.npz"):                      # with and without the suffix numpy appends
+        ck.save(a, tmp_path / name)
+        ck.load(b, tmp_path / name)
+        np.testing.assert_array_equal(b.params, a.params)
+        np.testing.assert_array_equal(b.running[2], a.running[2])
+        np.testing.assert_array_equal(b.adam, a.adam)
+        assert b.steps == 7
+    assert (tmp_path / "ckpt.npz").exists() and not (tmp_path / "ckpt2.npz.npz").exists()
+    # a file whose arrays do not fit the network is rejected before anything is copied in
+    with np.load(tmp_path / "ckpt.npz") as f:
+        arrays = {k: f[k] for k in f.files}
+    for key, bad in (("parameters", arrays["parameters"][:-1]), ("running_2", arrays["running_2"][:-2]),
+                     ("adam_state", arrays["adam_state"][:-3])):
+        broken = dict(arrays)
+        broken[key] = bad
+        np.savez(tmp_path / "broken.npz", **broken)
+        c = _FakeNet(3)
+        with pytest.raises(RuntimeError, match="checkpoint"):
+            ck.load(c, tmp_path / "broken")
+        assert c.writes == 0

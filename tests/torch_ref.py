@@ -76,6 +76,43 @@ def unet_graph(h=256, w=256, cin=3, base=64, depth=4, double_conv=True):
     return g
 
 
+def valid_unet_graph(h=60, w=60, cin=3, base=8, depth=2, acts=("relu", "relu")):
+    """The original U-Net geometry (Ronneberger et al.): unpadded 3x3 convolutions, 2x2 max pool, 2x2
+    transposed convolutions, the larger skip tensor centre-cropped at every concat; BASELINE config 4 at
+    572 x 572 / base 64 / depth 4 gives the 388 x 388 output.  `acts` = activations of the two convolutions of
+    a stage.  Returns (graph, output height, output width)."""
+    g = []
+
+    def conv(hh, ww, ci, co, parent, act):
+        g.append(("conv", [hh, ww, ci, co, 3, 0, 1], [] if parent is None else [parent], act))
+        return len(g) - 1, hh - 2, ww - 2
+
+    def stage(hh, ww, ci, co, parent):
+        i, hh, ww = conv(hh, ww, ci, co, parent, acts[0])
+        return conv(hh, ww, co, co, i, acts[1])
+
+    skips = []
+    cur, c, hh, ww = None, cin, h, w
+    for d in range(depth):
+        co = base << d
+        cur, hh, ww = stage(hh, ww, c, co, cur)
+        skips.append((cur, co))
+        assert hh % 2 == 0 and ww % 2 == 0, (hh, ww)
+        g.append(("pool", [co, hh, ww, 2, 2], [cur], None))
+        cur, c, hh, ww = len(g) - 1, co, hh // 2, ww // 2
+    cur, hh, ww = stage(hh, ww, c, base << depth, cur)
+    c = base << depth
+    for d in reversed(range(depth)):
+        skip, co = skips[d]
+        g.append(("up", [hh, ww, c, co, 2], [cur], None))
+        hh, ww = 2 * hh, 2 * ww
+        g.append(("concat", [], [skip, len(g) - 1], None))
+        cur, hh, ww = stage(hh, ww, 2 * co, co, len(g) - 1)
+        c = co
+    g.append(("conv", [hh, ww, c, 1, 3, 1, 1], [cur], "sigmoid"))
+    return g, hh, ww
+
+
 def attention_unet_graph(h=64, w=64, cin=3, f1=8):
     """The "Attention U-Net" graph the reference keeps commented out in main.py:144-184: the main.py
     graph with an attention gate on every skip connection (x = the encoder output, g = the decoder
@@ -167,6 +204,10 @@ def to_layer_descs(nn, graph):
     for kind, shape, parents, act in graph:
         if act == "sigmoid":
             out.append(nn.LayerDesc(kinds[kind], shape, parents, nn.ActivationType.SIGMOID))
+        elif act == "tanh":
+            out.append(nn.LayerDesc(kinds[kind], shape, parents, nn.ActivationType.TANH))
+        elif isinstance(act, str) and act.startswith("leaky:"):
+            out.append(nn.LayerDesc(kinds[kind], shape, parents, nn.ActivationType.LEAKY_ReLU, float(act[6:])))
         else:
             out.append(nn.LayerDesc(kinds[kind], shape, parents))
     return out
@@ -282,7 +323,8 @@ def _ulp_nudge(z, gen):
     return z + (moved.to(z.dtype) - z.detach())
 
 
-def forward(graph, params, x, training=True, running=None, emulate_bf16=False, nudge_seed=None, round_fp32=False):
+def forward(graph, params, x, training=True, running=None, emulate_bf16=False, nudge_seed=None, round_fp32=False,
+            pre=None):
     """x float64 [N,C,H,W] -> list of per-layer activations.  `running`
     (optional list of [mean,var] interleaved arrays per layer) is used when
     training=False.
@@ -298,11 +340,16 @@ def forward(graph, params, x, training=True, running=None, emulate_bf16=False, n
 
     nudge_seed: every convolution output is moved by +-1 fp32 ulp (seeded, per element) before it is
     rounded -- a second, equally valid evaluation of the same network, used to measure how far two correct
-    bf16 runs drift apart (tools/bf16_grad_sensitivity.py)."""
+    bf16 runs drift apart (tools/bf16_grad_sensitivity.py).
+
+    pre: a list that receives the batch-norm output (the activation's argument) of every conv / up layer."""
     gen = None if nudge_seed is None else torch.Generator().manual_seed(int(nudge_seed))
-    if round_fp32:   # every convolution output rounded to fp32 (what an fp32 engine stores), values only
+    if emulate_bf16:
+        rnd = _RoundBF16.apply
+    elif round_fp32:   # every convolution output rounded to fp32 (what an fp32 engine stores), values only
         rnd = lambda t: t + (t.detach().to(torch.float32).to(t.dtype) - t.detach())
-    rnd = _RoundBF16.apply if emulate_bf16 else (lambda t: t)
+    else:
+        rnd = lambda t: t
     rndw = _RoundBF16Value.apply if emulate_bf16 else (lambda t: t)
     if emulate_bf16:
         x = x.to(torch.bfloat16).to(x.dtype)
@@ -324,12 +371,25 @@ def forward(graph, params, x, training=True, running=None, emulate_bf16=False, n
             else:
                 r = torch.as_tensor(np.asarray(running[i], dtype=np.float64))
                 y = F.batch_norm(z, r[0::2], r[1::2], p["gamma"], p["beta"], training=False, eps=BN_EPS)
-            y = torch.sigmoid(y) if act == "sigmoid" else torch.relu(y)
+            if pre is not None:
+                pre.append(y.detach())
+            if act == "sigmoid":
+                y = torch.sigmoid(y)
+            elif act == "tanh" and kind == "conv":
+                y = torch.tanh(y)
+            elif isinstance(act, str) and act.startswith("leaky:") and kind == "conv":
+                y = F.leaky_relu(y, float(act[6:]))
+            else:
+                y = torch.relu(y)
             acts.append(y if i == last else rnd(y))
         elif kind == "pool":
             acts.append(_MaxPoolTies.apply(inp, s[3]) if emulate_bf16 else F.max_pool2d(inp, s[3], s[4]))
         elif kind == "concat":
-            acts.append(torch.cat([acts[parents[0]], acts[parents[1]]], dim=1))
+            a, b = acts[parents[0]], acts[parents[1]]
+            if a.shape[2:] != b.shape[2:]:   # the larger skip tensor is centre-cropped to the size of the one from below
+                oy, ox = (a.shape[2] - b.shape[2]) // 2, (a.shape[3] - b.shape[3]) // 2
+                a = a[:, :, oy:oy + b.shape[2], ox:ox + b.shape[3]]
+            acts.append(torch.cat([a, b], dim=1))
         elif kind == "attention":
             acts.append(rnd(attention_gate(acts[parents[0]], acts[parents[1]], params[i]["att"],
                                            attention_dims(graph, i)[2])))

@@ -17,9 +17,17 @@ respect to the reference; nn.ConvTranspose2d weight is (C_in, C_out, k, k) --
 the same; BatchNorm2d keeps weight (gamma), bias (beta), running_mean,
 running_var as separate vectors.
 """
+import os
+
 import numpy as np
 
 FORMAT_VERSION = 1
+
+
+def _npz_path(path):
+    """numpy.savez appends ".npz" to a name without that suffix; save() and load() agree on the result."""
+    path = os.fspath(path)
+    return path if path.endswith(".npz") else path + ".npz"
 
 
 def _layers(net):
@@ -52,23 +60,45 @@ def save(net, path, include_optimizer=True):
     if include_optimizer:
         arrays["adam_state"] = np.asarray(net.get_optimizer_state(), dtype=np.float32)
         arrays["adam_steps"] = np.int64(net.optimizer_steps())
-    np.savez(path, **arrays)
+    with open(_npz_path(path), "wb") as fh:
+        np.savez(fh, **arrays)
 
 
 def load(net, path, include_optimizer=True):
     """Restores what save() wrote into a network created from the same layer list."""
-    with np.load(path, allow_pickle=False) as f:
+    with np.load(_npz_path(path), allow_pickle=False) as f:
         if int(f["format_version"]) != FORMAT_VERSION:
             raise RuntimeError(f"unsupported checkpoint version {int(f['format_version'])}")
         layout = np.asarray(net.parameter_layout(), dtype=np.int64).reshape(-1, 4)
         if f["layout"].shape != layout.shape or not np.array_equal(f["layout"], layout):
             raise RuntimeError("the checkpoint was written by a network with a different layer list")
-        net.set_parameters(np.ascontiguousarray(f["parameters"], dtype=np.float32))
+        # every array is read and checked against the network before the first one is copied in, so that a
+        # truncated or edited file leaves the network as it was
+        n_params = int(net.num_parameters())
+        params = np.ascontiguousarray(f["parameters"], dtype=np.float32)
+        if params.size != n_params:
+            raise RuntimeError(f"checkpoint holds {params.size} parameters, the network has {n_params}")
+        running = {}
         for i, _, _, nbn in layout:
             if nbn:
-                net.set_running_stats(int(i), np.ascontiguousarray(f[f"running_{int(i)}"], dtype=np.float32))
+                key = f"running_{int(i)}"
+                if key not in f.files:
+                    raise RuntimeError(f"checkpoint has no running statistics for layer {int(i)}")
+                running[int(i)] = np.ascontiguousarray(f[key], dtype=np.float32)
+                if running[int(i)].size != int(nbn):
+                    raise RuntimeError(f"checkpoint: running statistics of layer {int(i)} have "
+                                       f"{running[int(i)].size} entries, expected {int(nbn)}")
+        adam = None
         if include_optimizer and "adam_state" in f.files:
-            net.set_optimizer_state(np.ascontiguousarray(f["adam_state"], dtype=np.float32), int(f["adam_steps"]))
+            adam = np.ascontiguousarray(f["adam_state"], dtype=np.float32)
+            if adam.size != 2 * n_params or "adam_steps" not in f.files:
+                raise RuntimeError(f"checkpoint: Adam state has {adam.size} entries, expected {2 * n_params}")
+            adam_steps = int(f["adam_steps"])
+    net.set_parameters(params)
+    for i, r in running.items():
+        net.set_running_stats(i, r)
+    if adam is not None:
+        net.set_optimizer_state(adam, adam_steps)
 
 
 def layer_to_torch(wb, c_in, c_out, k, transposed):

@@ -37,8 +37,13 @@ __device__ __forceinline__ bf16x8 tr_read_pair(const unsigned char *p0, const un
 // distance from a VALU write to a DPP read; the margin is wider because without the wait one build of the
 // transposed-convolution data-gradient kernel -- a packed fp32 multiply scheduled right before the rotation --
 // returned sums that differed between runs on identical inputs.
+#ifndef UNET_DPP_OPERAND_ASM
+#define UNET_DPP_OPERAND_ASM "s_nop 4"  // tools/dpp_lab.sh builds the library with other bodies ("" = no wait)
+#endif
 __device__ __forceinline__ float dpp_operand(float v) {
-  asm volatile("s_nop 4" : "+v"(v));
+#ifndef UNET_DPP_OPERAND_PLAIN
+  asm volatile(UNET_DPP_OPERAND_ASM : "+v"(v));
+#endif
   return v;
 }
 __device__ __forceinline__ float lane_rot_sum8(float v) {  // + lane (i + 8) % 16 of the same 16-lane row

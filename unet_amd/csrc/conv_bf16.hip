@@ -206,6 +206,7 @@ __global__ __launch_bounds__(256, (TAPS == 1 && BN == 64 && KC == 64) ? 3 : 2) v
   // bias of this workgroup's channels: one global load per thread into LDS (behind the staging buffers),
   // read back as broadcast 16-byte pieces in the epilogue
   constexpr int MAIN_BYTES = W_BYTES + NPIX * PITCH, EPI_BYTES = 256 * (BN * 2 + 16) + 2048;
+  static_assert(4 * BN * 2 * sizeof(float) <= 2048, "the 2048-byte slack holds the 4 waves x BN x 2 floats of the epilogue reduction");
   float *ldsB = reinterpret_cast<float *>(lds + (MAIN_BYTES > EPI_BYTES ? MAIN_BYTES : EPI_BYTES));
   float *ldsS = ldsB + BN;  // per-channel scale when a.affine (ldsB then holds the folded shift)
   if (!BRED && tid < BN) {

@@ -23,6 +23,16 @@ struct ReluF { __device__ float operator()(float x) const { return x > 0.f ? x :
 struct SigmF { __device__ float operator()(float x) const { return 1.0f / (1.0f + expf(-x)); } };
 struct ReluBwdF { __device__ float operator()(float dy, float x) const { return x > 0.f ? dy : 0.f; } };
 struct SigmBwdF { __device__ float operator()(float dy, float y) const { return dy * y * (1.0f - y); } };
+struct LeakyF {
+  float slope;
+  __device__ float operator()(float x) const { return x > 0.f ? x : slope * x; }
+};
+struct LeakyBwdF {
+  float slope;
+  __device__ float operator()(float dy, float x) const { return x > 0.f ? dy : slope * dy; }
+};
+struct TanhF { __device__ float operator()(float x) const { return tanhf(x); } };
+struct TanhBwdF { __device__ float operator()(float dy, float y) const { return dy * (1.0f - y * y); } };
 struct AddF { __device__ float operator()(float a, float b) const { return a + b; } };
 struct ThreshF {
   float t;
@@ -430,9 +440,31 @@ __global__ __launch_bounds__(256) void chan_copy_kernel(const float *__restrict_
   }
 }
 
+// Element i of the cropped window [N][Cs][Hb][Wb] <-> big[n][c][y + oy][x + ox] (big: [N][Cs][Ha][Wa]) and
+// cat[n][c][y][x] (cat: [N][Cd][Hb][Wb], channels 0..Cs-1).  BWD = false: cat <- big; true: big <- cat.
+template <bool BWD>
+__global__ __launch_bounds__(256) void crop_copy_kernel(const float *__restrict__ src, float *__restrict__ dst, i64 total,
+                                                        int Cs, int Cd, int Ha, int Wa, int Hb, int Wb, int oy, int ox) {
+  for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (i64)gridDim.x * blockDim.x) {
+    const int x = (int)(i % Wb);
+    i64 r = i / Wb;
+    const int y = (int)(r % Hb);
+    r /= Hb;
+    const int c = (int)(r % Cs);
+    const i64 n = r / Cs;
+    const i64 ib = ((n * Cs + c) * Ha + y + oy) * Wa + x + ox, ic = ((n * Cd + c) * Hb + y) * Wb + x;
+    if (BWD)
+      dst[ib] = src[ic];
+    else
+      dst[ic] = src[ib];
+  }
+}
+
 // ---- dice ------------------------------------------------------------------------
 // Sample n, slice blockIdx.y of its pixels -> out[(n*S + slice)*3 + {0,1,2}] (S = gridDim.y; with
-// S == 1 `out` is the loss_values array itself).
+// S == 1 `out` is the loss_values array itself).  SQ: slot 0 holds sum (p - m)^2 instead of sum m p (the
+// difference loss).
+template <bool SQ>
 __global__ __launch_bounds__(1024) void dice_sums_kernel(const float *__restrict__ mask,
                                                          const float *__restrict__ pred,
                                                          float *__restrict__ out, i64 HW) {
@@ -442,7 +474,7 @@ __global__ __launch_bounds__(1024) void dice_sums_kernel(const float *__restrict
   float acc[3] = {0.f, 0.f, 0.f};
   for (i64 i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
     const float m = mask[n * HW + i], p = pred[n * HW + i];
-    acc[0] += m * p;
+    acc[0] += SQ ? (p - m) * (p - m) : m * p;
     acc[1] += m;
     acc[2] += p;
   }
@@ -529,6 +561,20 @@ int unet_sigmoid_backward_f32(const float *grad_activations, const float *activa
                               float *grad_inputs, int64_t n, unet_stream_t s) {
   return launch_ew2(grad_activations, activations, grad_inputs, n, SigmBwdF(), s,
                     "unet_sigmoid_backward_f32");
+}
+int unet_leaky_relu_f32(const float *inputs, float *activations, int64_t n, float slope, unet_stream_t s) {
+  return launch_ew1(inputs, activations, n, LeakyF{slope}, s, "unet_leaky_relu_f32");
+}
+int unet_leaky_relu_backward_f32(const float *grad_activations, const float *inputs, float *grad_inputs, int64_t n,
+                                 float slope, unet_stream_t s) {
+  return launch_ew2(grad_activations, inputs, grad_inputs, n, LeakyBwdF{slope}, s, "unet_leaky_relu_backward_f32");
+}
+int unet_tanh_f32(const float *inputs, float *activations, int64_t n, unet_stream_t s) {
+  return launch_ew1(inputs, activations, n, TanhF(), s, "unet_tanh_f32");
+}
+int unet_tanh_backward_f32(const float *grad_activations, const float *activations, float *grad_inputs, int64_t n,
+                           unet_stream_t s) {
+  return launch_ew2(grad_activations, activations, grad_inputs, n, TanhBwdF(), s, "unet_tanh_backward_f32");
 }
 int unet_add_b_to_a_f32(float *a, const float *b, int64_t n, unet_stream_t s) {
   return launch_ew2(a, b, a, n, AddF(), s, "unet_add_b_to_a_f32");
@@ -865,9 +911,39 @@ int unet_concat_backward_f32(const float *dLdY, float *dLdX, int H, int W, int C
   return UNET_OK;
 }
 
+// Concat with the first tensor centre-cropped to the second one's size (see the header).
+int unet_concat_crop_f32(const float *a1, const float *a2, float *out, int N, int C1, int C2, int Ha, int Wa, int Hb,
+                         int Wb, unet_stream_t s) {
+  UNET_REQUIRE(N > 0 && C1 > 0 && C2 > 0 && Hb > 0 && Wb > 0 && Ha >= Hb && Wa >= Wb, "concat crop: bad sizes");
+  UNET_REQUIRE(a1 && a2 && out, "concat crop: NULL pointer");
+  const i64 total = (i64)N * C1 * Hb * Wb;
+  hipLaunchKernelGGL(crop_copy_kernel<false>, dim3(ew_grid(total)), dim3(256), 0, as_stream(s), a1, out, total, C1, C1 + C2,
+                     Ha, Wa, Hb, Wb, (Ha - Hb) / 2, (Wa - Wb) / 2);
+  UNET_LAUNCH_CHECK("crop_copy_kernel");
+  hipLaunchKernelGGL(chan_copy_kernel, dim3(ew_grid((i64)N * C2 * Hb * Wb)), dim3(256), 0, as_stream(s), a2, out,
+                     (i64)Hb * Wb, C2, C1 + C2, C1, N, 1);
+  UNET_LAUNCH_CHECK("chan_copy_kernel");
+  return UNET_OK;
+}
+int unet_concat_crop_backward_f32(const float *dLdY, float *dA, float *dB, int N, int C1, int C2, int Ha, int Wa, int Hb,
+                                  int Wb, unet_stream_t s) {
+  UNET_REQUIRE(N > 0 && C1 > 0 && C2 > 0 && Hb > 0 && Wb > 0 && Ha >= Hb && Wa >= Wb, "concat crop backward: bad sizes");
+  UNET_REQUIRE(dLdY && dA && dB, "concat crop backward: NULL pointer");
+  UNET_HIP_TRY(hipMemsetAsync(dA, 0, sizeof(float) * (size_t)N * C1 * Ha * Wa, as_stream(s)));
+  const i64 total = (i64)N * C1 * Hb * Wb;
+  hipLaunchKernelGGL(crop_copy_kernel<true>, dim3(ew_grid(total)), dim3(256), 0, as_stream(s), dLdY, dA, total, C1, C1 + C2,
+                     Ha, Wa, Hb, Wb, (Ha - Hb) / 2, (Wa - Wb) / 2);
+  UNET_LAUNCH_CHECK("crop_copy_kernel");
+  hipLaunchKernelGGL(chan_copy_kernel, dim3(ew_grid((i64)N * C2 * Hb * Wb)), dim3(256), 0, as_stream(s), dLdY, dB,
+                     (i64)Hb * Wb, C2, C1 + C2, C1, N, 0);
+  UNET_LAUNCH_CHECK("chan_copy_kernel");
+  return UNET_OK;
+}
+
 // ---- losses ------------------------------------------------------------------------
-int unet_dice_sums_f32(const float *mask, const float *prediction, int H, int W, int N,
-                       float *loss_values, unet_stream_t s) {
+static int loss_sums_launch(bool sq, const float *mask, const float *prediction, int H, int W, int N,
+                            float *loss_values, unet_stream_t s) {
+  auto kernel = sq ? dice_sums_kernel<true> : dice_sums_kernel<false>;
   UNET_REQUIRE(N > 0 && H > 0 && W > 0, "dice: need positive sizes");
   UNET_REQUIRE(mask && prediction && loss_values, "dice: NULL pointer");
   const i64 HW = (i64)H * W;
@@ -875,19 +951,27 @@ int unet_dice_sums_f32(const float *mask, const float *prediction, int H, int W,
   const i64 cap = (HW + 4095) / 4096;                     // at least 4 K pixels per slice
   if (S > cap) S = (int)cap;
   if (S <= 1) {
-    hipLaunchKernelGGL(dice_sums_kernel, dim3(N, 1), dim3(1024), 0, as_stream(s), mask, prediction, loss_values, HW);
+    hipLaunchKernelGGL(kernel, dim3(N, 1), dim3(1024), 0, as_stream(s), mask, prediction, loss_values, HW);
     UNET_LAUNCH_CHECK("dice_sums_kernel");
     return UNET_OK;
   }
   void *ws;
   int rc = unet_workspace(&ws, sizeof(float) * 3 * (size_t)N * S, as_stream(s));
   if (rc) return rc;
-  hipLaunchKernelGGL(dice_sums_kernel, dim3(N, S), dim3(1024), 0, as_stream(s), mask, prediction, (float *)ws, HW);
+  hipLaunchKernelGGL(kernel, dim3(N, S), dim3(1024), 0, as_stream(s), mask, prediction, (float *)ws, HW);
   UNET_LAUNCH_CHECK("dice_sums_kernel");
   hipLaunchKernelGGL(dice_sums_finish_kernel, dim3(cdiv_u(3 * N, 64)), dim3(64), 0, as_stream(s), (const float *)ws,
                      loss_values, N, S);
   UNET_LAUNCH_CHECK("dice_sums_finish_kernel");
   return UNET_OK;
+}
+int unet_dice_sums_f32(const float *mask, const float *prediction, int H, int W, int N, float *loss_values,
+                       unet_stream_t s) {
+  return loss_sums_launch(false, mask, prediction, H, W, N, loss_values, s);
+}
+int unet_difference_loss_sums_f32(const float *mask, const float *prediction, int H, int W, int N, float *loss_values,
+                                  unet_stream_t s) {
+  return loss_sums_launch(true, mask, prediction, H, W, N, loss_values, s);
 }
 int unet_dice_score_f32(const float *mask, const float *prediction, int H, int W, int N,
                         float *loss_values, float *dice_host, unet_stream_t s) {

@@ -241,6 +241,10 @@ int unet_malloc(void **ptr, size_t bytes) {
   if (bytes == 0) bytes = 4;
   UNET_HIP_TRY(hipMalloc(ptr, bytes));
   UNET_HIP_TRY(hipMemset(*ptr, 0, bytes));
+  // The fill runs on the null stream and may still be queued when hipMemset returns (behind work of the
+  // blocking streams).  A non-blocking stream does not wait for it: without this wait, a copy enqueued on
+  // one right after the allocation could land first and then be zeroed.
+  UNET_HIP_TRY(hipStreamSynchronize(nullptr));
   return UNET_OK;
 }
 int unet_free(void *ptr) {

@@ -37,14 +37,15 @@ class NN {
     if (ii.ndim != 4) throw std::runtime_error("images must have shape [N, C, H, W]");
     if (mi.ndim != 3) throw std::runtime_error("masks must have shape [N, H, W]");
     const int64_t N = ii.shape[0], C = ii.shape[1], H = ii.shape[2], W = ii.shape[3];
-    if (N != mi.shape[0] || H != mi.shape[1] || W != mi.shape[2])
-      throw std::runtime_error("Mask dimensions do not equal image dimensions");
     check_input(C, H, W);
+    check_mask(N, mi.shape[0], mi.shape[1], mi.shape[2]);
     if (batch_size < 1) throw std::runtime_error("Batch size must be greater than 0");
     const float *img = static_cast<const float *>(ii.ptr);
     const float *msk = static_cast<const float *>(mi.ptr);
+    const unet::Node &f = net_.nodes()[net_.final_layer()];
+    const int64_t mask_hw = (int64_t)f.out_h * f.out_w;
     run_epochs(N, batch_size, epochs, learning_rate, [&](int slot, int64_t start, int count) {
-      net_.stage_batch_host(slot, img + start * C * H * W, msk + start * H * W, count);
+      net_.stage_batch_host(slot, img + start * C * H * W, msk + start * mask_hw, count);
     });
   }
 
@@ -72,28 +73,39 @@ class NN {
           const int64_t nstart = start + batch_size;
           stage((int)((b + 1) & 1), nstart, (int)std::min<int64_t>(batch_size, N - nstart));
         }
-        if (net_.loss() == LossFunction::kDiceLoss)
-          UNET_CALL(unet_memcpy_d2d(epoch_lv.f32() + 3 * (size_t)batch_size * b, net_.loss_values_ptr(),
-                                    sizeof(float) * 3 * cur, net_.stream()));
+        UNET_CALL(unet_memcpy_d2d(epoch_lv.f32() + 3 * (size_t)batch_size * b, net_.loss_values_ptr(),
+                                  sizeof(float) * 3 * cur, net_.stream()));
       }
       net_.sync();
       const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-      double total_dice = 0;
-      if (net_.loss() == LossFunction::kDiceLoss) {
-        UNET_CALL(unet_memcpy_d2h(lv.data(), epoch_lv.raw(), sizeof(float) * lv.size(), 1, net_.stream()));
-        for (int64_t b = 0; b < nb; ++b) {
-          const int cur = (int)std::min<int64_t>(batch_size, N - b * batch_size);
-          for (int i = 0; i < cur; ++i) {
-            const float *s = &lv[3 * ((size_t)batch_size * b + i)];
-            total_dice += 2.0 * s[0] / (s[1] + s[2] + 1e-5);
-          }
+      // Dice loss: 1 - mean Dice score, as the reference prints.  Difference loss: the mean over the
+      // epoch's batches of 0.5 * mean (y - m)^2 (the reference prints the Dice figures of an unrelated,
+      // never-filled buffer there); no Dice score is measured, so none is reported.
+      const bool is_dice = net_.loss() == LossFunction::kDiceLoss;
+      const unet::Node &f = net_.nodes()[net_.final_layer()];
+      double total = 0;
+      UNET_CALL(unet_memcpy_d2h(lv.data(), epoch_lv.raw(), sizeof(float) * lv.size(), 1, net_.stream()));
+      for (int64_t b = 0; b < nb; ++b) {
+        const int cur = (int)std::min<int64_t>(batch_size, N - b * batch_size);
+        double batch_sq = 0;
+        for (int i = 0; i < cur; ++i) {
+          const float *s = &lv[3 * ((size_t)batch_size * b + i)];
+          if (is_dice)
+            total += 2.0 * s[0] / (s[1] + s[2] + 1e-5);
+          else
+            batch_sq += s[0];
         }
+        if (!is_dice) total += 0.5 * batch_sq / ((double)cur * f.out_h * f.out_w);
       }
-      last_epoch_loss_ = (float)(1.0 - total_dice / (double)N);
+      const double avg_loss = is_dice ? 1.0 - total / (double)N : total / (double)nb;
+      last_epoch_loss_ = (float)avg_loss;
       if (v) {
         std::cout << "ephoch " << epoch << " done." << std::endl;
-        std::cout << "average loss: " << 1.0 - total_dice / (double)N << std::endl;
-        std::cout << "average dice score: " << total_dice / (double)N << std::endl;
+        std::cout << "average loss: " << avg_loss << std::endl;
+        if (is_dice)
+          std::cout << "average dice score: " << total / (double)N << std::endl;
+        else
+          std::cout << "average dice score: n/a (difference loss)" << std::endl;
         std::cout << "images/s: " << (double)N / secs << std::endl;
       }
     }
@@ -250,9 +262,8 @@ class NN {
   float train_step(farray images, farray masks, float learning_rate, bool do_step) {
     py::buffer_info ii = images.request(), mi = masks.request();
     if (ii.ndim != 4 || mi.ndim != 3) throw std::runtime_error("need images [N,C,H,W] and masks [N,H,W]");
-    if (ii.shape[0] != mi.shape[0] || ii.shape[2] != mi.shape[1] || ii.shape[3] != mi.shape[2])
-      throw std::runtime_error("Mask dimensions do not equal image dimensions");
     check_input(ii.shape[1], ii.shape[2], ii.shape[3]);
+    check_mask(ii.shape[0], mi.shape[0], mi.shape[1], mi.shape[2]);
     const int batch = (int)ii.shape[0];
     net_.train_batch_host(static_cast<const float *>(ii.ptr), static_cast<const float *>(mi.ptr), batch,
                           learning_rate, do_step);
@@ -304,6 +315,13 @@ class NN {
          << ", " << net_.in_h() << ", " << net_.in_w() << "]";
       throw std::runtime_error(ss.str());
     }
+  }
+  // Masks have the size of the network OUTPUT: the image size for the padded convolutions of main.py (the
+  // reference's check, neural_net.h:137-140), smaller for graphs of unpadded convolutions.
+  void check_mask(int64_t n_images, int64_t n_masks, int64_t h, int64_t w) {
+    const unet::Node &f = net_.nodes()[net_.final_layer()];
+    if (n_images != n_masks || h != f.out_h || w != f.out_w)
+      throw std::runtime_error("Mask dimensions do not equal image dimensions");
   }
   void run_forward(const float *host_images, int batch, bool inference) {
     net_.ensure_batch(batch);

@@ -22,6 +22,7 @@
 #include <sstream>
 #include <stdexcept>
 #include <string>
+#include <limits>
 #include <vector>
 
 #include "layer_desc.h"
@@ -96,6 +97,8 @@ struct Node {
   int in_c = 0, in_h = 0, in_w = 0, out_c = 0, out_h = 0, out_w = 0;
   int kernel = 0, padding = 0, stride = 1;
   int c1 = 0, c2 = 0;  // concat: channels of the two parents
+  int crop_h = 0, crop_w = 0;  // concat: size of the first parent when it is larger and gets centre-cropped (else 0)
+  float leaky = 0.01f;         // LEAKY_ReLU slope (LayerDesc::leaky_const)
   std::vector<int> input_shape, output_shape;
   // parameters: slice [param_off, param_off + num_wb + num_bn) of the flat
   // buffers, laid out [weights | biases | gamma0,beta0,...] like the
@@ -284,6 +287,8 @@ class Net {
     Node &f = nodes_[final_];
     if (loss_ == LossFunction::kDiceLoss)
       UNET_CALL(unet_dice_sums_f32(masks, f.act.f32(), f.out_h, f.out_w, batch, loss_values_.f32(), stream_));
+    else
+      UNET_CALL(unet_difference_loss_sums_f32(masks, f.act.f32(), f.out_h, f.out_w, batch, loss_values_.f32(), stream_));
   }
 
   void backward_device(const float *images, const float *masks, int batch) {
@@ -457,23 +462,19 @@ class Net {
   float last_loss(int batch, float *dice_out = nullptr) {
     const Node &f = nodes_[final_];
     sync();
+    std::vector<float> lv(3 * (size_t)batch);
+    UNET_CALL(unet_memcpy_d2h(lv.data(), loss_values_.raw(), sizeof(float) * lv.size(), 1, stream_));
     if (loss_ == LossFunction::kDiceLoss) {
-      std::vector<float> lv(3 * (size_t)batch);
-      UNET_CALL(unet_memcpy_d2h(lv.data(), loss_values_.raw(), sizeof(float) * lv.size(), 1, stream_));
       float dice = 0.f;
       for (int i = 0; i < batch; ++i) dice += 2.0f * lv[3 * i] / (lv[3 * i + 1] + lv[3 * i + 2] + 1e-5f);
       dice /= (float)batch;
       if (dice_out) *dice_out = dice;
       return 1.0f - dice;
     }
-    const size_t n = (size_t)batch * f.out_h * f.out_w;
-    std::vector<float> y(n), m(n);
-    UNET_CALL(unet_memcpy_d2h(y.data(), f.act.raw(), sizeof(float) * n, 1, stream_));
-    UNET_CALL(unet_memcpy_d2h(m.data(), in_masks_.raw(), sizeof(float) * n, 1, stream_));
     double s = 0;
-    for (size_t i = 0; i < n; ++i) s += 0.5 * (double)(y[i] - m[i]) * (y[i] - m[i]);
-    if (dice_out) *dice_out = 0.f;
-    return (float)(s / (double)n);
+    for (int i = 0; i < batch; ++i) s += lv[3 * i];
+    if (dice_out) *dice_out = std::numeric_limits<float>::quiet_NaN();  // not measured under this loss
+    return (float)(0.5 * s / ((double)batch * f.out_h * f.out_w));
   }
 
   void sync() { UNET_CALL(unet_stream_synchronize(stream_)); }
@@ -616,6 +617,8 @@ class Net {
       n.grad_out.ensure(out_bytes);
       max_out = std::max(max_out, n.out_elems());
       int64_t in_e = n.type == CONCAT_LAYER ? n.out_elems() : n.in_elems();
+      if (n.type == CONCAT_LAYER && n.crop_h)
+        in_e = (int64_t)n.c1 * n.crop_h * n.crop_w + (int64_t)n.c2 * n.in_h * n.in_w;
       if (n.type == ATTENTION_LAYER) {
         const size_t cells = b * (size_t)(n.in_h / 2) * (n.in_w / 2);
         n.z.ensure(sizeof(float) * cells * n.att_ci());  // int_1: the ReLU output of the additive projection
@@ -645,6 +648,7 @@ class Net {
     n.type = d.type;
     n.parents = d.parents;
     n.activation = d.activation;
+    n.leaky = (float)d.leaky_const;
     const std::vector<int> &s = d.descriptor;
     auto parent = [&](int i) -> const Node & { return nodes_[n.parents[i]]; };
     switch (d.type) {
@@ -699,14 +703,21 @@ class Net {
           throw std::runtime_error(ss.str());
         }
         const Node &a = parent(0), &b = parent(1);
-        if (a.out_h != b.out_h || a.out_w != b.out_w) {
+        // A larger first parent (the skip of a U-Net of unpadded convolutions) is centre-cropped to the second
+        // one's size when the margins are even; the reference rejects every size mismatch (layer.h:523-533).
+        const bool crop = a.out_h >= b.out_h && a.out_w >= b.out_w && (a.out_h != b.out_h || a.out_w != b.out_w) &&
+                          (a.out_h - b.out_h) % 2 == 0 && (a.out_w - b.out_w) % 2 == 0;
+        if (crop) {
+          n.crop_h = a.out_h;
+          n.crop_w = a.out_w;
+        } else if (a.out_h != b.out_h || a.out_w != b.out_w) {
           std::stringstream ss;
           ss << "Concat layer must have equal heights and widths. Height and width of parent 1: " << a.out_h
              << ", " << a.out_w << " Height and width of parent 2: " << b.out_h << ", " << b.out_w;
           throw std::runtime_error(ss.str());
         }
         n.c1 = a.out_c; n.c2 = b.out_c;
-        n.in_c = n.c1 + n.c2; n.in_h = a.out_h; n.in_w = a.out_w;
+        n.in_c = n.c1 + n.c2; n.in_h = b.out_h; n.in_w = b.out_w;
         n.out_c = n.in_c; n.out_h = n.in_h; n.out_w = n.in_w;
         n.input_shape = {n.c1, n.c2, n.in_h, n.in_w};
         break;
@@ -788,6 +799,16 @@ class Net {
     }
   }
 
+  // The activation a CONV / UPSAMPLING layer applies.  SIGMOID, TANH and LEAKY_ReLU are what they say (on
+  // convolution layers); every other value -- NONE, the LayerDesc default that main.py:187-224 relies on,
+  // included -- is ReLU, as in the reference (convolution_layer_functions.h:59-65,
+  // upsampling_layer_functions.h:57-65).
+  static Activation_type effective_activation(const Node &n) {
+    if (n.type == CONV_LAYER && (n.activation == SIGMOID || n.activation == TANH || n.activation == LEAKY_ReLU))
+      return n.activation;
+    return ReLU;
+  }
+
   const float *layer_input(const Node &n, const float *images) const {
     return n.parents.empty() ? images : nodes_[n.parents[0]].act.f32();
   }
@@ -813,10 +834,12 @@ class Net {
         else
           UNET_CALL(unet_batch_norm_train_f32(n.z.f32(), n.bn.f32(), gb, n.batch_stats.f32(), n.running.f32(),
                                               n.out_c, n.out_h, n.out_w, batch, stream_));
-        if (n.type == CONV_LAYER && n.activation == SIGMOID)
-          UNET_CALL(unet_sigmoid_f32(n.bn.f32(), n.act.f32(), out_n, stream_));
-        else
-          UNET_CALL(unet_relu_f32(n.bn.f32(), n.act.f32(), out_n, stream_));
+        switch (effective_activation(n)) {
+          case SIGMOID: UNET_CALL(unet_sigmoid_f32(n.bn.f32(), n.act.f32(), out_n, stream_)); break;
+          case TANH: UNET_CALL(unet_tanh_f32(n.bn.f32(), n.act.f32(), out_n, stream_)); break;
+          case LEAKY_ReLU: UNET_CALL(unet_leaky_relu_f32(n.bn.f32(), n.act.f32(), out_n, n.leaky, stream_)); break;
+          default: UNET_CALL(unet_relu_f32(n.bn.f32(), n.act.f32(), out_n, stream_));
+        }
         break;
       }
       case MAX_POOL_LAYER:
@@ -824,8 +847,12 @@ class Net {
                                     n.in_w, stream_));
         break;
       case CONCAT_LAYER:
-        UNET_CALL(unet_concat_f32(nodes_[n.parents[0]].act.f32(), nodes_[n.parents[1]].act.f32(), n.act.f32(), batch,
-                                  (int64_t)n.in_h * n.in_w, n.c1, n.c2, stream_));
+        if (n.crop_h)
+          UNET_CALL(unet_concat_crop_f32(nodes_[n.parents[0]].act.f32(), nodes_[n.parents[1]].act.f32(), n.act.f32(),
+                                         batch, n.c1, n.c2, n.crop_h, n.crop_w, n.in_h, n.in_w, stream_));
+        else
+          UNET_CALL(unet_concat_f32(nodes_[n.parents[0]].act.f32(), nodes_[n.parents[1]].act.f32(), n.act.f32(), batch,
+                                    (int64_t)n.in_h * n.in_w, n.c1, n.c2, stream_));
         break;
       case ATTENTION_LAYER:  // attention_layer_functions.h:4-28
         UNET_CALL(unet_attention_f32(n.z.f32(), n.bn.f32(), n.act.f32(), params_.f32() + n.param_off,
@@ -858,10 +885,14 @@ class Net {
         const float *w = params_.f32() + n.param_off;
         float *gw = grads_.f32() + n.param_off;
         float *g2 = scratch_g2_.f32(), *g1 = scratch_g1_.f32();
-        if (n.type == CONV_LAYER && n.activation == SIGMOID)
-          UNET_CALL(unet_sigmoid_backward_f32(n.grad_out.f32(), n.act.f32(), g2, out_n, stream_));
-        else
-          UNET_CALL(unet_relu_backward_f32(n.grad_out.f32(), n.bn.f32(), g2, out_n, stream_));
+        switch (effective_activation(n)) {
+          case SIGMOID: UNET_CALL(unet_sigmoid_backward_f32(n.grad_out.f32(), n.act.f32(), g2, out_n, stream_)); break;
+          case TANH: UNET_CALL(unet_tanh_backward_f32(n.grad_out.f32(), n.act.f32(), g2, out_n, stream_)); break;
+          case LEAKY_ReLU:
+            UNET_CALL(unet_leaky_relu_backward_f32(n.grad_out.f32(), n.bn.f32(), g2, out_n, n.leaky, stream_));
+            break;
+          default: UNET_CALL(unet_relu_backward_f32(n.grad_out.f32(), n.bn.f32(), g2, out_n, stream_));
+        }
         UNET_CALL(unet_batch_norm_backward_f32(g2, n.z.f32(), n.batch_stats.f32(), w + n.num_wb, g1, gw + n.num_wb,
                                                n.out_c, n.out_h, n.out_w, batch, stream_));
         float *dx = nullptr;
@@ -888,8 +919,13 @@ class Net {
       case CONCAT_LAYER: {
         // true split: [N,C1,H,W] to parent 0, [N,C2,H,W] to parent 1
         float *tmp = scratch_dx_.f32();
-        UNET_CALL(unet_concat_backward_f32(n.grad_out.f32(), tmp, n.in_h, n.in_w, n.c1, n.c2, batch, stream_));
-        const int64_t n1 = (int64_t)batch * n.c1 * n.in_h * n.in_w, n2 = (int64_t)batch * n.c2 * n.in_h * n.in_w;
+        const int64_t n1 = (int64_t)batch * n.c1 * (n.crop_h ? (int64_t)n.crop_h * n.crop_w : (int64_t)n.in_h * n.in_w);
+        const int64_t n2 = (int64_t)batch * n.c2 * n.in_h * n.in_w;
+        if (n.crop_h)  // the skip tensor's gradient is zero outside the cropped window
+          UNET_CALL(unet_concat_crop_backward_f32(n.grad_out.f32(), tmp, tmp + n1, batch, n.c1, n.c2, n.crop_h, n.crop_w,
+                                                  n.in_h, n.in_w, stream_));
+        else
+          UNET_CALL(unet_concat_backward_f32(n.grad_out.f32(), tmp, n.in_h, n.in_w, n.c1, n.c2, batch, stream_));
         Node &a = nodes_[n.parents[0]], &b = nodes_[n.parents[1]];
         commit_copy(a, tmp, n1);
         commit_copy(b, tmp + n1, n2);
@@ -969,6 +1005,7 @@ class Net {
       switch (n.type) {
         case CONV_LAYER:
           if (n.kernel != 3 || n.padding != 1 || n.stride != 1) return why = "a convolution that is not 3x3/pad 1/stride 1", false;
+          if (n.activation == TANH || n.activation == LEAKY_ReLU) return why = "an activation other than ReLU / sigmoid", false;
           if (n.parents.empty() ? n.in_c > 32 : n.in_c % 32 != 0) return why = "a convolution whose C_in is not a multiple of 32", false;
           if (n.out_c % 32 != 0) {
             if (!is_final || n.out_c > 32) return why = "a hidden convolution whose C_out is not a multiple of 32", false;
@@ -985,6 +1022,7 @@ class Net {
           break;
         case CONCAT_LAYER:
           if (n.c1 % 32 || n.c2 % 32 || n.concat_child >= 0 || is_final) return why = "a concat with channel counts off multiples of 32", false;
+          if (n.crop_h) return why = "a concat that crops its first parent", false;
           break;
         case ATTENTION_LAYER:
           // the gate's projections run in fp32 inside unet_attention_bf16; its tensors stay NHWC bf16
