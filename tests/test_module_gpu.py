@@ -105,8 +105,12 @@ def test_create_validation_messages(nn):
                                L(T.CONV_LAYER, [8, 8, 3, 4, 3, 1, 1], [])], nn.DICE_LOSS)
     with pytest.raises(RuntimeError, match="Concat layer must have two parents"):
         nn.NeuralNet().create([L(T.CONV_LAYER, [8, 8, 3, 4, 3, 1, 1], []), L(T.CONCAT_LAYER, [], [0])], nn.DICE_LOSS)
+    # a smaller first parent, or odd margins, cannot be centre-cropped to the second parent's size
     with pytest.raises(RuntimeError, match="equal heights and widths"):
         nn.NeuralNet().create([L(T.CONV_LAYER, [8, 8, 3, 4, 3, 1, 1], []), L(T.MAX_POOL_LAYER, [4, 8, 8, 2, 2], [0]),
+                               L(T.CONCAT_LAYER, [], [1, 0])], nn.DICE_LOSS)
+    with pytest.raises(RuntimeError, match="equal heights and widths"):
+        nn.NeuralNet().create([L(T.CONV_LAYER, [9, 9, 3, 4, 3, 1, 1], []), L(T.CONV_LAYER, [9, 9, 4, 4, 3, 0, 2], [0]),
                                L(T.CONCAT_LAYER, [], [0, 1])], nn.DICE_LOSS)
     with pytest.raises(RuntimeError, match="does not equal output shape of parent"):
         nn.NeuralNet().create([L(T.CONV_LAYER, [8, 8, 3, 4, 3, 1, 1], []), L(T.UPSAMPLING_LAYER, [8, 8, 5, 4, 2], [0])],

@@ -54,3 +54,36 @@ for rep in range(1, REPS):
               " which:", sorted(set(idx[:, 2].tolist())),
               " max rel diff", float(np.max(np.abs(outs[rep][1] - outs[0][1])[dpt] / (np.abs(outs[0][1])[dpt] + 1e-20))))
 print(f"{ndiff} of {REPS - 1} repeats differ from the first run")
+
+# For rows that differ between runs: which run is right, and by how much is the other one off?  The reference
+# is recomputed here from the kernel's own (deterministic) dx output: per 16x16 tile and channel,
+# sum g*xhat = (sum g*z - mean * sum g) * invstd with g = dx where a*z + b > 0.
+if ndiff and os.environ.get("EXPLAIN", "1") == "1":
+    dxf = torch.from_numpy(outs[0][0]).view(torch.bfloat16).float()          # [n, h, w, cp]
+    zf = zp.float().cpu()
+    cf = torch.from_numpy(coef_h)                                            # [cp, 4]: a, b, mean, invstd
+    g = torch.where(cf[:, 0] * zf + cf[:, 1] > 0, dxf, torch.zeros(()))
+    tw = (w + 15) // 16
+    shown = 0
+    for rep in range(1, REPS):
+        dpt = outs[rep][1] != outs[0][1]
+        for row in sorted(set(np.argwhere(dpt)[:, 0].tolist())):
+            if shown >= 6:
+                break
+            shown += 1
+            nn_, tile = divmod(row, tiles)
+            ty, tx = divmod(tile, tw)
+            gs = g[nn_, ty * 16:ty * 16 + 16, tx * 16:tx * 16 + 16].double()
+            zs = zf[nn_, ty * 16:ty * 16 + 16, tx * 16:tx * 16 + 16].double()
+            ref = ((gs * zs).sum((0, 1)) - cf[:, 2].double() * gs.sum((0, 1))) * cf[:, 3].double()
+            # the same per group of pixels one wave sums: pixels p with (p % 32) // 8 == wave
+            pix = torch.arange(256).reshape(16, 16)
+            chans = sorted(set(np.argwhere(dpt[row])[:, 0].tolist()))
+            print(f"run {rep} row {row} (image {nn_}, tile {ty},{tx}):")
+            for c in chans[:8]:
+                per_wave = []
+                for wv in range(4):
+                    m = ((pix % 32) // 8 == wv)
+                    per_wave.append(float((((gs[..., c] * zs[..., c])[m]).sum() - cf[c, 2].double() * gs[..., c][m].sum()) * cf[c, 3].double()))
+                print(f"   ch {c:3d}: run0 {outs[0][1][row, c, 0]:+.6f}  run{rep} {outs[rep][1][row, c, 0]:+.6f}  reference {float(ref[c]):+.6f}"
+                      f"  per-wave reference {[round(v, 5) for v in per_wave]}")

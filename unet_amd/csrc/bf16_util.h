@@ -29,34 +29,55 @@ __device__ __forceinline__ bf16x8 tr_read_pair(const unsigned char *p0, const un
 
 // Sum over the lanes of a wavefront that share (lane % CH), CH a power of two in [4, 32]; every lane gets
 // the total.  The stages inside a 16-lane row are DPP row rotations (VALU, no LDS traffic); the two stages
-// across rows are __shfl_xor (ds_bpermute_b32).  The gfx950 lane-swap instructions (v_permlane16/32_swap)
-// make those VALU-only as well; without a wait on their operand the sums varied from run to run (see
-// dpp_operand below), with it they are exact but no faster on the whole step, so they are not used.
-// The operand passes through a wait (s_nop 4, tied to the register): whatever VALU instruction produced it then
-// retires at least five wait states before the DPP instruction reads it across lanes.  Two is the documented
-// distance from a VALU write to a DPP read; the margin is wider because without the wait one build of the
-// transposed-convolution data-gradient kernel -- a packed fp32 multiply scheduled right before the rotation --
-// returned sums that differed between runs on identical inputs.
+// across rows are __shfl_xor (ds_bpermute_b32).
+//
+// keep_scalar(): an empty asm statement tied to the value's register.  Its only effect is on code shape: the
+// arithmetic that produced the value is emitted as scalar fp32 instructions instead of being paired with a
+// neighbour's into packed ones.  It is here because of one measured failure.  In the epilogue of the
+// transposed-convolution data gradient with the fused batch-norm reduction (conv_mfma_kernel<1, 64, true, 64>,
+// three workgroups per CU) the products (sum g*z - mean * sum g) * invstd were compiled to
+//     v_pk_fma_f32 ... op_sel:[0,1,1] op_sel_hi:[1,0,0]   (low result from the operands' high halves)
+//     v_mov_b32    vN, w
+//     v_pk_mul_f32 v[M:M+1], v[N:N+1], v[M:M+1]            (upper halves unused)
+// and that build returned, on identical inputs, sums that differed between runs: only sum g*xhat, only the
+// channels whose product went through the op_sel form, only in workgroups that retire while others are being
+// launched on the CU (batches that fit one round of resident workgroups never showed it).  What the
+// laboratory builds (tools/dpp_lab.sh, tools/diag_tconv_bred.py, tools/pk_hazard_lab*.hip) established:
+//   - it is not a DPP hazard: the nearest VALU producer sits 19 instructions before the first row rotation
+//     (tools/dpp_hazard_scan.py), and a build with every stage through ds_bpermute_b32 fails as often;
+//   - wait states do not matter: s_nop 0, s_nop 4 and an empty asm all cure it (0 of 59 repeats differ, 29-35
+//     of 59 without), and s_nop 7, s_waitcnt vmcnt(0) / lgkmcnt(0) or s_barrier pinned in front of the packed
+//     block (keeping it packed) do not;
+//   - the 34 instructions replayed verbatim in a kernel of their own (same registers, same unused halves,
+//     with and without workgroup turnover) gave 0 wrong products of 2.8e10.
+// So the cause is neither of the documented hazards and is not isolated; the packed form is avoided here and
+// test_fused_bn_reduction_is_bit_identical_between_runs keeps watch.
 #ifndef UNET_DPP_OPERAND_ASM
-#define UNET_DPP_OPERAND_ASM "s_nop 4"  // tools/dpp_lab.sh builds the library with other bodies ("" = no wait)
+#define UNET_DPP_OPERAND_ASM ""  // tools/dpp_lab.sh builds the library with other bodies
 #endif
-__device__ __forceinline__ float dpp_operand(float v) {
+__device__ __forceinline__ float keep_scalar(float v) {
 #ifndef UNET_DPP_OPERAND_PLAIN
   asm volatile(UNET_DPP_OPERAND_ASM : "+v"(v));
 #endif
   return v;
 }
 __device__ __forceinline__ float lane_rot_sum8(float v) {  // + lane (i + 8) % 16 of the same 16-lane row
-  v = dpp_operand(v);
+  v = keep_scalar(v);
   return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xf, 0xf, true));
 }
 __device__ __forceinline__ float lane_rot_sum4(float v) {  // + lane (i + 4) % 16 of the same 16-lane row
-  v = dpp_operand(v);
+  v = keep_scalar(v);
   return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124, 0xf, 0xf, true));
 }
 template <int CH>
 __device__ __forceinline__ float lane_class_sum(float v) {
   static_assert(CH == 4 || CH == 8 || CH == 16 || CH == 32, "lane_class_sum: CH must be 4, 8, 16 or 32");
+#ifdef UNET_LAB_NO_DPP  // tools/dpp_lab.sh: every stage through ds_bpermute_b32
+  if (CH <= 4) v += __shfl_xor(v, 4, 64);
+  if (CH <= 8) v += __shfl_xor(v, 8, 64);
+  if (CH <= 16) v += __shfl_xor(v, 16, 64);
+  return v + __shfl_xor(v, 32, 64);
+#endif
   if (CH <= 4) {
     v = lane_rot_sum8(v);  // {i, i+8}
     v = lane_rot_sum4(v);  // {i, i+4, i+8, i+12}: the row's lanes of this class

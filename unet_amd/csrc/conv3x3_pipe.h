@@ -63,13 +63,13 @@ struct Args {
 };
 
 __device__ __forceinline__ float row_sum16(float v) {  // sum over the 16 lanes of a DPP row, in every lane
-  v = dpp_operand(v);
+  v = keep_scalar(v);
   v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xf, 0xf, true));
-  v = dpp_operand(v);
+  v = keep_scalar(v);
   v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124, 0xf, 0xf, true));
-  v = dpp_operand(v);
+  v = keep_scalar(v);
   v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x122, 0xf, 0xf, true));
-  v = dpp_operand(v);
+  v = keep_scalar(v);
   v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x121, 0xf, 0xf, true));
   return v;
 }
@@ -91,19 +91,19 @@ constexpr int epi_vmem_ops(int epi) {  // vector-memory instructions a wave issu
 // Lanes 16 apart exchange halves (v_permlane16_swap: odd 16-lane rows of the first operand <-> even rows of
 // the second).  In: hw[m] = the lane's 4 channels (2 dwords) of 16-channel block m, lane row kp holding
 // channels 4 kp .. 4 kp + 3.  Out: 16 bytes = 8 consecutive channels of block (kp & 1), from channel
-// 8 (kp >> 1).  The operands pass through a wait first (see dpp_operand): they come straight from VALU
-// conversions.  unswap16 is the inverse (the exchange is an involution).
+// 8 (kp >> 1).  The operands are tied to registers of their own first (see keep_scalar in bf16_util.h).
+// unswap16 is the inverse (the exchange is an involution).
 typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ i32x4 swap16(const u32x2_t (&hw)[2]) {
   unsigned a0 = hw[0].x, a1 = hw[0].y, b0 = hw[1].x, b1 = hw[1].y;
-  asm volatile("s_nop 4" : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1));
+  asm volatile("" : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1));
   const u32x2_t lo = __builtin_amdgcn_permlane16_swap(a0, b0, false, false);
   const u32x2_t hi = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
   return i32x4{(int)lo.x, (int)hi.x, (int)lo.y, (int)hi.y};
 }
 __device__ __forceinline__ void unswap16(const i32x4 &v, u32x2_t (&hw)[2]) {
   unsigned p0 = (unsigned)v.x, p1 = (unsigned)v.y, q0 = (unsigned)v.z, q1 = (unsigned)v.w;
-  asm volatile("s_nop 4" : "+v"(p0), "+v"(p1), "+v"(q0), "+v"(q1));
+  asm volatile("" : "+v"(p0), "+v"(p1), "+v"(q0), "+v"(q1));
   const u32x2_t lo = __builtin_amdgcn_permlane16_swap(p0, q0, false, false);
   const u32x2_t hi = __builtin_amdgcn_permlane16_swap(p1, q1, false, false);
   hw[0] = u32x2_t{lo.x, hi.x};

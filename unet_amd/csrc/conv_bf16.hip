@@ -390,6 +390,11 @@ __global__ __launch_bounds__(256, (TAPS == 1 && BN == 64 && KC == 64) ? 3 : 2) v
     }
   }
   if (BRED && red_here) {  // sum g*xhat = (sum g*z - mean * sum g) / sqrt(var + eps)
+#ifdef UNET_LAB_BRED_FENCE  // tools/dpp_lab.sh: an instruction pinned here in laboratory builds
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile(UNET_LAB_BRED_FENCE ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
     for (int j = 0; j < 8; ++j) ssum[j] = (ssum[j] - bcf[j].z * ssq[j]) * bcf[j].w;
   }
