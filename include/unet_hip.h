@@ -112,6 +112,12 @@ int unet_init_bn_f32(float *weights, int64_t num_weights, unet_stream_t stream);
 /* Replaces cudaHasNans (cuda_ops.cu:649-675) with an on-device scan:
  * *has_nan_host = 1 when any element is NaN.  Synchronises `stream`. */
 int unet_has_nans_f32(const float *ptr, int64_t num_floats, int *has_nan_host, unet_stream_t stream);
+/* The same question without a synchronisation, for a check on every training step (the reference calls
+ * cudaHasNans from inside its convolution layer when debugging, convolution_layer_functions.h:69-71):
+ * *flag_device, an int in device memory that the caller zeroed once, becomes `value` (non-zero, e.g. the step
+ * number) if it still was 0 and some element of ptr[0..num_floats) is NaN or +-Inf.  Asynchronous on `stream`;
+ * read the flag whenever the host synchronises anyway.  ptr must be 16-byte aligned. */
+int unet_flag_nonfinite_f32(const float *ptr, int64_t num_floats, int *flag_device, int value, unet_stream_t stream);
 
 /* ---- convolution (cuda_lib.h:44-58, 162-177) ---------------------------- */
 

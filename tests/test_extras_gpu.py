@@ -158,3 +158,37 @@ def test_difference_loss_value():
                              torch.from_numpy(x).double(), training=True)
     ref = torch_ref.difference_loss(acts[-1], torch.from_numpy(mk).double()).item()
     assert abs(got - ref) <= 1e-4 * ref
+
+
+def test_nonfinite_gradient_watch(oracle):
+    """unet_flag_nonfinite_f32 records the first call that saw a NaN or Inf; the module raises from train_step()
+    when the watch is on (set_check_nan / UNET_CHECK_NAN=1) and says at which optimizer step."""
+    import neural_net as nn
+    xh = np.linspace(-1, 1, 1003).astype(np.float32)
+    x = dev(xh)
+    flag = torch.zeros(1, dtype=torch.int32, device=x.device)
+    capi.unet_flag_nonfinite_f32(p(x), xh.size, p(flag), 5, None)
+    assert int(flag.item()) == 0
+    for pos, bad in ((1002, np.inf), (17, np.nan), (400, -np.inf)):
+        y = xh.copy()
+        y[pos] = bad
+        flag.zero_()
+        yd = dev(y)
+        capi.unet_flag_nonfinite_f32(p(yd), y.size, p(flag), 7, None)
+        capi.unet_flag_nonfinite_f32(p(yd), y.size, p(flag), 9, None)      # the first record stays
+        assert int(flag.item()) == 7
+
+    graph = torch_ref.main_py_graph(16, 16, 3, 4)
+    net = nn.NeuralNet()
+    net.create(torch_ref.to_layer_descs(nn, graph), nn.LossFunction.DICE_LOSS)
+    net.set_check_nan(True)
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((2, 3, 16, 16)).astype(np.float32)
+    m = (rng.random((2, 16, 16)) < 0.3).astype(np.float32)
+    net.train_step(x, m, 1e-3, True)
+    net.train_step(x, m, 1e-3, True)
+    assert net.nonfinite_step() == 0
+    x[1, 2, 3, 4] = np.nan
+    with pytest.raises(RuntimeError, match="first seen at optimizer step 3"):
+        net.train_step(x, m, 1e-3, True)
+    assert net.nonfinite_step() == 3

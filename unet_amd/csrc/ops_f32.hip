@@ -159,6 +159,23 @@ __global__ __launch_bounds__(256) void has_nan_kernel(const float *x, i64 n, int
     bad |= (x[i] != x[i]);
   if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
 }
+// *flag <- value if *flag was 0 and some x[i] is NaN or +-Inf
+__global__ __launch_bounds__(256) void nonfinite_flag_kernel(const float *__restrict__ x, i64 n, int *flag, int value) {
+  int bad = 0;
+  const i64 n4 = n >> 2;
+  const float4 *x4 = reinterpret_cast<const float4 *>(x);
+  for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (i64)gridDim.x * blockDim.x) {
+    const float4 v = x4[i];
+    // x - x is 0 for finite x and NaN otherwise
+    const float t = (v.x - v.x) + (v.y - v.y) + (v.z - v.z) + (v.w - v.w);
+    bad |= (t != 0.0f);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const float v = x[(n4 << 2) + threadIdx.x];
+    bad |= (v - v != 0.0f);
+  }
+  if (__any(bad) && (threadIdx.x & 63) == 0) atomicCAS(flag, 0, value);
+}
 
 // ---- batch norm ---------------------------------------------------------------
 // Channel c's elements are the N planes x[(n*C+c)*HW .. +HW).  A block reduces
@@ -653,6 +670,15 @@ int unet_has_nans_f32(const float *ptr, int64_t n, int *has_nan_host, unet_strea
   UNET_LAUNCH_CHECK("has_nan_kernel");
   UNET_HIP_TRY(hipMemcpyAsync(has_nan_host, ws, 4, hipMemcpyDeviceToHost, as_stream(s)));
   UNET_HIP_TRY(hipStreamSynchronize(as_stream(s)));
+  return UNET_OK;
+}
+int unet_flag_nonfinite_f32(const float *ptr, int64_t n, int *flag_device, int value, unet_stream_t s) {
+  UNET_REQUIRE(flag_device && value != 0, "unet_flag_nonfinite_f32: need a flag pointer and a non-zero value");
+  if (!ptr || n <= 0) return UNET_OK;
+  UNET_REQUIRE(((uintptr_t)ptr & 15) == 0, "unet_flag_nonfinite_f32: the array must be 16-byte aligned");
+  hipLaunchKernelGGL(nonfinite_flag_kernel, dim3(ew_grid((n + 3) / 4)), dim3(256), 0, as_stream(s), ptr, (i64)n,
+                     flag_device, value);
+  UNET_LAUNCH_CHECK("nonfinite_flag_kernel");
   return UNET_OK;
 }
 

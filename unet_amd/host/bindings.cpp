@@ -23,6 +23,8 @@ class NN {
  public:
   NN() {
     if (std::getenv("UNET_QUIET")) net_.set_verbose(false);
+    const char *nan = std::getenv("UNET_CHECK_NAN");
+    if (nan && nan[0] && nan[0] != '0') net_.set_check_nan(true);
     if (net_.verbose()) std::cout << "initializing NN" << std::endl << std::flush;
     UNET_CALL(unet_device_reset());
   }
@@ -78,6 +80,7 @@ class NN {
       }
       net_.sync();
       const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      net_.raise_if_nonfinite();
       // Dice loss: 1 - mean Dice score, as the reference prints.  Difference loss: the mean over the
       // epoch's batches of 0.5 * mean (y - m)^2 (the reference prints the Dice figures of an unrelated,
       // never-filled buffer there); no Dice score is measured, so none is reported.
@@ -258,6 +261,10 @@ class NN {
     net_.copy_optimizer_state_from_host(static_cast<const float *>(bi.ptr), step_count);
   }
   int optimizer_steps() const { return net_.step_count(); }
+  // Watch for NaN / Inf gradients on every step (also switched on by UNET_CHECK_NAN=1): train(), train_step()
+  // raise once such a step has been seen; nonfinite_step() returns that step (1-based) or 0.
+  void set_check_nan(bool on) { net_.set_check_nan(on); }
+  int nonfinite_step() { return net_.nonfinite_step(); }
   // forward + loss + backward (+ Adam step when lr > 0 ... see do_step); returns the loss
   float train_step(farray images, farray masks, float learning_rate, bool do_step) {
     py::buffer_info ii = images.request(), mi = masks.request();
@@ -463,6 +470,8 @@ PYBIND11_MODULE(neural_net, m) {
       .def("broadcast_state", &NN::broadcast_state)
       .def("parameters_changed", &NN::parameters_changed)
       .def("last_epoch_loss", &NN::last_epoch_loss)
+      .def("set_check_nan", &NN::set_check_nan)
+      .def("nonfinite_step", &NN::nonfinite_step)
       .def("compute_dtype", &NN::compute_dtype);
 
   py::class_<Convolution>(m, "Convolution")

@@ -328,11 +328,36 @@ class Net {
   // step counter for the whole network).
   void step_device(float learning_rate) {
     if (comm_) UNET_CALL(unet_allreduce_wait(comm_, stream_));  // every bucket's mean over the ranks has landed
+    flag_nonfinite_gradients();
     ++step_count_;
     UNET_CALL(unet_update_weights_adam_f32(params_.f32(), grads_.f32(), adam_.f32(), learning_rate,
                                            total_params_, step_count_, stream_));
     params_dirty_ = true;
     inf_coef_valid_ = false;
+  }
+
+  // ---- per-step NaN / Inf watch (UNET_CHECK_NAN=1 or set_check_nan): one asynchronous pass over the gradient
+  // vector per step records the first optimizer step whose gradients were not finite; the host looks at the
+  // record where it synchronises anyway (last_loss, the end of an epoch) and raises there.
+  void set_check_nan(bool on) { check_nan_ = on; }
+  bool check_nan() const { return check_nan_; }
+  void flag_nonfinite_gradients() {
+    if (!check_nan_) return;
+    nan_flag_.ensure(sizeof(int));
+    UNET_CALL(unet_flag_nonfinite_f32(grads_.f32(), total_params_, static_cast<int *>(nan_flag_.raw()), step_count_ + 1,
+                                      stream_));
+  }
+  // 0, or the optimizer step (1-based) at which non-finite gradients were first seen.  Synchronises.
+  int nonfinite_step() {
+    if (!nan_flag_.raw()) return 0;
+    int v = 0;
+    UNET_CALL(unet_memcpy_d2h(&v, nan_flag_.raw(), sizeof(int), 1, stream_));
+    return v;
+  }
+  void raise_if_nonfinite() {
+    if (!check_nan_) return;
+    const int at = nonfinite_step();
+    if (at) throw std::runtime_error("NaN or Inf in the gradients, first seen at optimizer step " + std::to_string(at));
   }
 
   // ---- host-facing helpers ----------------------------------------------------
@@ -348,7 +373,10 @@ class Net {
     forward_device(in_images_.f32(), batch, false);
     loss_forward_device(in_masks_.f32(), batch);
     backward_device(in_images_.f32(), in_masks_.f32(), batch);
-    if (do_step) step_device(lr);
+    if (do_step)
+      step_device(lr);
+    else
+      flag_nonfinite_gradients();
   }
 
   // ---- double-buffered input feed for train(): while the GPU works on batch b, the host copies
@@ -464,6 +492,7 @@ class Net {
     sync();
     std::vector<float> lv(3 * (size_t)batch);
     UNET_CALL(unet_memcpy_d2h(lv.data(), loss_values_.raw(), sizeof(float) * lv.size(), 1, stream_));
+    raise_if_nonfinite();
     if (loss_ == LossFunction::kDiceLoss) {
       float dice = 0.f;
       for (int i = 0; i < batch; ++i) dice += 2.0f * lv[3 * i] / (lv[3 * i + 1] + lv[3 * i + 2] + 1e-5f);
@@ -1444,6 +1473,8 @@ class Net {
   DeviceBuffer x16_;      // network input as NHWC bf16, channels padded to in_cp()
   DeviceBuffer dz16_;     // scratch: gradient w.r.t. a layer's pre-BN output
   bool verbose_ = true;
+  bool check_nan_ = false;
+  DeviceBuffer nan_flag_;
   unet_stream_t stream_ = nullptr;
   int64_t bucket_bytes_ = 8 << 20;
   std::vector<Bucket> buckets_;
