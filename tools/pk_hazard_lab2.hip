@@ -5,6 +5,7 @@
 // arithmetic on the same operands.  JUNK selects what the unused halves (v3, v5, v7) hold before the replay.
 //   hipcc --offload-arch=gfx950 -O2 tools/pk_hazard_lab2.hip -o tools/bin/pk_hazard_lab2
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -128,6 +129,61 @@ __global__ __launch_bounds__(256, 3) void lab_kernel(unsigned long long *bad, un
   if (n_bad) atomicAdd(bad, n_bad);
 }
 
+// A co-runner for the second stream: every wave issues MFMAs back to back for `iters` rounds.
+typedef __bf16 lab_bf16x8 __attribute__((ext_vector_type(8)));
+typedef float lab_f32x16 __attribute__((ext_vector_type(16)));
+template <bool VGPR_FORM>
+__global__ __launch_bounds__(256, 1) void mfma_spin_kernel(float *out, int iters) {
+  lab_bf16x8 a, b;
+  for (int i = 0; i < 8; ++i) {
+    a[i] = (__bf16)(float)(threadIdx.x % 7);
+    b[i] = (__bf16)(float)(threadIdx.x % 5);
+  }
+  lab_f32x16 acc0 = {}, acc1 = {}, acc2 = {}, acc3 = {};
+  for (int it = 0; it < iters; ++it) {
+    if (VGPR_FORM) {  // accumulators in ordinary vector registers
+      asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc0) : "v"(a), "v"(b));
+      asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc1) : "v"(a), "v"(b));
+      asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc2) : "v"(a), "v"(b));
+      asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc3) : "v"(a), "v"(b));
+    } else {          // accumulators in the accumulation registers
+      asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc0) : "v"(a), "v"(b));
+      asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc1) : "v"(a), "v"(b));
+      asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc2) : "v"(a), "v"(b));
+      asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc3) : "v"(a), "v"(b));
+    }
+  }
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+  float t = 0.f;
+  for (int i = 0; i < 16; ++i) t += acc0[i] + acc1[i] + acc2[i] + acc3[i];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = t;
+}
+
+// Co-runners that isolate one ingredient of the library's weight-gradient kernel each.
+typedef short lab_s16x4 __attribute__((ext_vector_type(4)));
+template <int KIND>  // 0: transposing LDS reads (ds_read_b64_tr_b16)  1: plain 8-byte LDS reads  2: VALU only (v_pk_fma)
+__global__ __launch_bounds__(256, 1) void spin2_kernel(float *out, int iters) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[16384];
+  for (int i = threadIdx.x; i < 4096; i += 256) reinterpret_cast<unsigned *>(lds)[i] = i * 2654435761u;
+  __syncthreads();
+  unsigned acc = 0;
+  float f0 = 1.0f, f1 = 2.0f;
+  const unsigned char *p = lds + (threadIdx.x & 63) * 8 + (threadIdx.x >> 6) * 2048;
+  for (int it = 0; it < iters; ++it) {
+    if (KIND == 0) {
+      const lab_s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+          (__attribute__((address_space(3))) lab_s16x4 *)(__attribute__((address_space(3))) void *)(p + (it & 3) * 512));
+      acc += (unsigned)v[0] + (unsigned)v[3];
+    } else if (KIND == 1) {
+      const uint2 v = *reinterpret_cast<const uint2 *>(p + (it & 3) * 512);
+      acc += v.x + v.y;
+    } else {
+      asm volatile("v_pk_fma_f32 %0, %0, %0, %0" : "+v"(*reinterpret_cast<double *>(&f0)));
+    }
+  }
+  out[blockIdx.x * blockDim.x + threadIdx.x] = (float)acc + f0 + f1;
+}
+
 #define CHECK(x)                                              \
   do {                                                        \
     hipError_t e_ = (x);                                      \
@@ -147,11 +203,51 @@ int main(int argc, char **argv) {
   CHECK(hipMalloc(&bad, sizeof(*bad)));
   CHECK(hipMalloc(&bad_j, sizeof(*bad_j)));
   CHECK(hipMalloc(&sink, sizeof(uint4) * blocks * threads));
-  const unsigned junks[] = {0x00007f12u, 0x7fc00000u, 0x7f800000u, 0xffff0000u, 0x3f800000u, 0x00000000u};
+  // third argument: rounds of the MFMA co-runner on a second stream (0 = none); it runs one 256-lane workgroup
+  // per CU beside the replay's workgroups
+  const int mfma_iters = argc > 3 ? atoi(argv[3]) : 0;
+  hipStream_t s_main, s_side;
+  CHECK(hipStreamCreateWithFlags(&s_main, hipStreamNonBlocking));
+  CHECK(hipStreamCreateWithFlags(&s_side, hipStreamNonBlocking));
+  float *spin_out;
+  CHECK(hipMalloc(&spin_out, sizeof(float) * 256 * 256));
+  typedef int (*wgrad_fn)(const void *, int, const void *, int, float *, int, int, int, int, int, int, int, void *);
+  wgrad_fn wgrad = nullptr;
+  void *wg_dz = nullptr, *wg_x = nullptr;
+  float *wg_g = nullptr;
+  if (mfma_iters < 0) {
+    const char *libname = getenv("UNET_LAB_LIB") ? getenv("UNET_LAB_LIB") : "unet_amd/lib/libunet_hip.so";
+    void *h = dlopen(libname, RTLD_NOW);
+    if (!h) {
+      fprintf(stderr, "dlopen: %s\n", dlerror());
+      return 1;
+    }
+    wgrad = (wgrad_fn)dlsym(h, "unet_conv3x3_wgrad_bf16");
+    CHECK(hipMalloc(&wg_dz, 2 * 16 * 16 * 16 * 1024));
+    CHECK(hipMalloc(&wg_x, 2 * 16 * 16 * 16 * 512));
+    CHECK(hipMalloc(&wg_g, sizeof(float) * 512 * 1024 * 9));
+    CHECK(hipMemset(wg_dz, 0x3c, 2 * 16 * 16 * 16 * 1024));
+    CHECK(hipMemset(wg_x, 0x3c, 2 * 16 * 16 * 16 * 512));
+  }
+  const unsigned junks[] = {0x00007f12u, 0x7fc00000u, 0x3f800000u};
   for (unsigned junk : junks) {
     CHECK(hipMemset(bad, 0, sizeof(*bad)));
     CHECK(hipMemset(bad_j, 0, sizeof(*bad_j)));
-    hipLaunchKernelGGL(lab_kernel, dim3(blocks), dim3(threads), 0, 0, bad, bad_j, sink, iters, junk);
+    CHECK(hipDeviceSynchronize());
+    const int kind = argc > 4 ? atoi(argv[4]) : -1;  // fourth argument: which co-runner
+    if (mfma_iters > 0 && kind == -1)  // MFMA loop, accumulators in the accumulation registers
+      hipLaunchKernelGGL(mfma_spin_kernel<false>, dim3(256), dim3(256), 0, s_side, spin_out, mfma_iters);
+    if (mfma_iters > 0 && kind == -2)  // MFMA loop, accumulators in ordinary vector registers
+      hipLaunchKernelGGL(mfma_spin_kernel<true>, dim3(256), dim3(256), 0, s_side, spin_out, mfma_iters);
+    if (mfma_iters > 0 && kind == 0) hipLaunchKernelGGL(spin2_kernel<0>, dim3(256), dim3(256), 0, s_side, spin_out, mfma_iters);
+    if (mfma_iters > 0 && kind == 1) hipLaunchKernelGGL(spin2_kernel<1>, dim3(256), dim3(256), 0, s_side, spin_out, mfma_iters);
+    if (mfma_iters < 0)  // the library's 3x3 weight-gradient kernel as the co-runner, -mfma_iters launches
+      for (int i = 0; i < -mfma_iters; ++i)
+        if (wgrad(wg_dz, 1024, wg_x, 512, wg_g, 16, 16, 16, 512, 1024, 512, 1024, s_side)) {
+          fprintf(stderr, "wgrad call failed\n");
+          return 1;
+        }
+    hipLaunchKernelGGL(lab_kernel, dim3(blocks), dim3(threads), 0, s_main, bad, bad_j, sink, iters, junk);
     CHECK(hipGetLastError());
     CHECK(hipDeviceSynchronize());
     unsigned long long h = 0;

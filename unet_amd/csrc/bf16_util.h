@@ -33,25 +33,31 @@ __device__ __forceinline__ bf16x8 tr_read_pair(const unsigned char *p0, const un
 //
 // keep_scalar(): an empty asm statement tied to the value's register.  Its only effect is on code shape: the
 // arithmetic that produced the value is emitted as scalar fp32 instructions instead of being paired with a
-// neighbour's into packed ones.  It is here because of one measured failure.  In the epilogue of the
-// transposed-convolution data gradient with the fused batch-norm reduction (conv_mfma_kernel<1, 64, true, 64>,
-// three workgroups per CU) the products (sum g*z - mean * sum g) * invstd were compiled to
-//     v_pk_fma_f32 ... op_sel:[0,1,1] op_sel_hi:[1,0,0]   (low result from the operands' high halves)
-//     v_mov_b32    vN, w
-//     v_pk_mul_f32 v[M:M+1], v[N:N+1], v[M:M+1]            (upper halves unused)
-// and that build returned, on identical inputs, sums that differed between runs: only sum g*xhat, only the
-// channels whose product went through the op_sel form, only in workgroups that retire while others are being
-// launched on the CU (batches that fit one round of resident workgroups never showed it).  What the
-// laboratory builds (tools/dpp_lab.sh, tools/diag_tconv_bred.py, tools/pk_hazard_lab*.hip) established:
-//   - it is not a DPP hazard: the nearest VALU producer sits 19 instructions before the first row rotation
-//     (tools/dpp_hazard_scan.py), and a build with every stage through ds_bpermute_b32 fails as often;
-//   - wait states do not matter: s_nop 0, s_nop 4 and an empty asm all cure it (0 of 59 repeats differ, 29-35
-//     of 59 without), and s_nop 7, s_waitcnt vmcnt(0) / lgkmcnt(0) or s_barrier pinned in front of the packed
-//     block (keeping it packed) do not;
-//   - the 34 instructions replayed verbatim in a kernel of their own (same registers, same unused halves,
-//     with and without workgroup turnover) gave 0 wrong products of 2.8e10.
-// So the cause is neither of the documented hazards and is not isolated; the packed form is avoided here and
-// test_fused_bn_reduction_is_bit_identical_between_runs keeps watch.
+// neighbour's into packed ones (v_pk_fma_f32 / v_pk_mul_f32).  It is here because of a measured failure of the
+// packed form on this hardware: packed fp32 arithmetic of one wave returned wrong results while waves of an
+// MFMA kernel of this library ran on the same SIMD.
+//   - First seen in the epilogue of the transposed-convolution data gradient with the fused batch-norm
+//     reduction (conv_mfma_kernel<1, 64, true, 64>, three workgroups per CU): the products
+//     (sum g*z - mean * sum g) * invstd, compiled to
+//         v_pk_fma_f32 ... op_sel:[0,1,1] op_sel_hi:[1,0,0]   (low result from the operands' high halves)
+//         v_mov_b32    vN, w
+//         v_pk_mul_f32 v[M:M+1], v[N:N+1], v[M:M+1]            (upper halves unused)
+//     differed between runs on identical inputs -- only sum g*xhat, only the channels whose product went
+//     through the op_sel form, only in workgroups that retire while others (in their MFMA loops) run on the CU;
+//     batches that fit one round of resident workgroups never showed it.
+//   - Then in the pooled batch-norm backward reduction (fused_bf16.hip) running beside the 3x3 weight-gradient
+//     kernel on a second stream: wrong sums of g*xhat for half of the lanes, every input intact.
+//   - Reproduced outside the library: the 34 instructions of the first case replayed verbatim in a kernel of
+//     their own give 0 wrong products of 2.5e9 alone, beside loops of MFMAs (either accumulator form), of
+//     transposing or plain LDS reads, and beside the weight-gradient kernel with its MFMAs removed -- and about
+//     4500 wrong ones (even channels only: the op_sel form) beside the real weight-gradient kernel
+//     (tools/pk_hazard_lab2.hip, tools/corun_lab.sh).
+// What it is not: a DPP hazard (the nearest producer sits 19 instructions before the first row rotation, and a
+// build without any DPP instruction fails alike), a matter of wait states (s_nop 0, s_nop 4 and the empty asm all
+// cure it; s_nop 7, s_waitcnt vmcnt(0) / lgkmcnt(0) or s_barrier pinned in front of the packed block do not), or
+// clobbered inputs.  The mechanism inside the SIMD is not isolated further; the packed form is avoided where a
+// result feeds a reduction (here, conv3x3_pipe.h, the pooled reduction), and two tests keep watch:
+// test_fused_bn_reduction_is_bit_identical_between_runs and tests/test_concurrency_gpu.py.
 #ifndef UNET_DPP_OPERAND_ASM
 #define UNET_DPP_OPERAND_ASM ""  // tools/dpp_lab.sh builds the library with other bodies
 #endif

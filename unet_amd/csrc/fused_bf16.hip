@@ -438,7 +438,13 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_pool_kernel(const bf16_t *_
       for (int k = 0; k < 4; ++k)
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          s[2 * j] += g[k][j] * ((zv[k][j] - c[j].mean) * c[j].invb);
+          // xhat stays a scalar product (empty asm tied to its register): compiled to packed fp32 instructions
+          // this kernel needed 245 registers instead of 162 and, worse, returned wrong sums of g*xhat whenever
+          // its waves shared a SIMD with waves of one of the MFMA kernels running on another stream (the
+          // sum of g, computed beside it, stayed right); see keep_scalar in bf16_util.h
+          float xh = (zv[k][j] - c[j].mean) * c[j].invb;
+          asm volatile("" : "+v"(xh));
+          s[2 * j] += g[k][j] * xh;
           s[2 * j + 1] += g[k][j];
         }
     }

@@ -152,9 +152,14 @@ __global__ __launch_bounds__(256, 1) void wgrad_mfma_kernel(const WgradArgs a) {
 #pragma unroll
           for (int kh = 0; kh < 3; ++kh) {
             const int ks = r - kh;
-            if (ks >= 0 && ks < 8)
+            if (ks >= 0 && ks < 8) {
+#ifdef WGRAD_LAB_NO_MFMA  // tools/corun_lab.sh: the same operands through VALU instead of the matrix cores
+              acc[(TAPS == 9) ? kh * 3 + kw : 0][0] += (float)aw[ks % 3][0] * (float)bfr[0];
+#else
               acc[(TAPS == 9) ? kh * 3 + kw : 0] =
                   __builtin_amdgcn_mfma_f32_32x32x16_bf16(aw[ks % 3], bfr, acc[(TAPS == 9) ? kh * 3 + kw : 0], 0, 0, 0);
+#endif
+            }
           }
         }
       }
