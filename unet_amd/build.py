@@ -19,7 +19,12 @@ LIBDIR = os.path.join(ROOT, "unet_amd", "lib")
 OBJDIR = os.path.join(ROOT, "build", "obj")
 HIP_LIB = os.path.join(LIBDIR, "libunet_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
+# -fno-slp-vectorize: the SLP vectoriser pairs independent fp32 operations into packed instructions
+# (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32).  On MI355X such arithmetic returned wrong results in waves that
+# shared a SIMD with waves of this library's MFMA kernels (csrc/bf16_util.h, keep_scalar); the scalar form never
+# did.  Without the pass the device code holds almost no packed fp32 arithmetic, and the training step takes the
+# same time (7.27 ms either way: these kernels are bound by HBM or by the matrix cores, not by VALU issue).
+HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize", "-Wall", "-Wno-unused-function",
              "-Wno-unused-variable", "-Wno-unused-but-set-variable"]
 # Per-file extra flags.  wgrad_bf16: MFMA accumulators stay in ordinary vector registers (no copies
 # to and from the accumulation half of the register file around the loop-carried accumulators).

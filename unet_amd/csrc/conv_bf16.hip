@@ -360,9 +360,11 @@ __global__ __launch_bounds__(256, (TAPS == 1 && BN == 64 && KC == 64) ? 3 : 2) v
           const uint32_t vw = vv[j >> 1], zw = zz[j >> 1];
           const float dy = (j & 1) ? bf16_to_f32(vw >> 16) : bf16_to_f32(vw & 0xffffu);
           const float zv = (j & 1) ? bf16_to_f32(zw >> 16) : bf16_to_f32(zw & 0xffffu);
-          const float g = fmaf(bcf[j].x, zv, bcf[j].y) > 0.f ? dy : 0.f;
-          ssum[j] = fmaf(g, zv, ssum[j]);  // sum g*z; turned into sum g*xhat after the loop
-          ssq[j] += g;
+          // g and the two sums stay scalar arithmetic (see keep_scalar in bf16_util.h: the packed form went
+          // wrong beside waves of another MFMA kernel)
+          const float g = keep_scalar(fmaf(bcf[j].x, zv, bcf[j].y) > 0.f ? dy : 0.f);
+          ssum[j] = keep_scalar(fmaf(g, zv, ssum[j]));  // sum g*z; turned into sum g*xhat after the loop
+          ssq[j] = keep_scalar(ssq[j] + g);
         }
       } else if (stats) {
         const uint32_t vv[4] = {v.x, v.y, v.z, v.w};
