@@ -202,11 +202,16 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(device)
 
-    # Timer families -> kernels.  The forward and data-gradient 3x3 convolutions are the same
-    # kernel (conv_mfma_kernel<9,64>; the data gradient runs it on flipped weights).
-    kernel_of = {"conv3x3_fwd_bf16": "conv_mfma_kernel<9,64>", "conv3x3_dgrad_bf16": "conv_mfma_kernel<9,64>",
+    # Timer families -> kernels.  The forward and data-gradient 3x3 convolutions are the same kernels (the
+    # data gradient runs them on flipped weights): conv3x3_pipe_kernel for images of at least 32 x 16 pixels
+    # with enough tiles to fill the device, conv_mfma_kernel<9,64> for the rest (16 x 16 layers here).
+    CONV3 = "conv3x3_pipe_kernel+conv_mfma_kernel<9,64>"
+    kernel_of = {"conv3x3_fwd_bf16": CONV3, "conv3x3_dgrad_bf16": CONV3,
                  "conv3x3_wgrad_bf16": "wgrad_mfma_kernel<9>", "tconv2x2_bf16": "conv_mfma_kernel<1,64>",
                  "tconv2x2_wgrad_bf16": "wgrad_mfma_kernel<1>"}
+    # substrings of the rocprofv3 kernel names that belong to a group (for the counter-derived traffic)
+    trace_names = {CONV3: ("conv3x3_pipe_kernel<", "conv_mfma_kernel<9, 64,"), "wgrad_mfma_kernel<9>": ("wgrad_mfma_kernel<9>",),
+                   "conv_mfma_kernel<1,64>": ("conv_mfma_kernel<1, 64,",), "wgrad_mfma_kernel<1>": ("wgrad_mfma_kernel<1>",)}
 
     def read_families():
         fams = {}
@@ -306,7 +311,7 @@ def main():
         "final_loss": loss,
     }
     if families:
-        mfma_bound = {"conv_mfma_kernel<9,64>", "wgrad_mfma_kernel<9>", "conv_mfma_kernel<1,64>",
+        mfma_bound = {CONV3, "wgrad_mfma_kernel<9>", "conv_mfma_kernel<1,64>",
                       "wgrad_mfma_kernel<1>", "conv_fwd_f32", "conv_dgrad_f32", "conv_wgrad_f32", "tconv_f32"}
         # dominant kernel = the one with the largest share of device time in the probe pass; its
         # launches were timed live in the timed region
@@ -330,12 +335,11 @@ def main():
                             args.base == 64 and dtype == "bf16")
         traffic = json.load(open(tpath)) if default_workload and os.path.exists(tpath) else {}
         # the counters describe one build of the kernels: a file collected on other sources is not reported
-        if traffic.get("_source_hash") == source_hash("conv_bf16.hip", "wgrad_bf16.hip", "bf16_util.h"):
-            # "conv_mfma_kernel<9,64>" covers the template instances "conv_mfma_kernel<9, 64, false|true>"
-            # (without / with the fused batch-norm-backward reduction): launch-weighted mean
-            want = name.replace(",", ", ")[:-1]
+        if traffic.get("_source_hash") == source_hash("conv_bf16.hip", "conv3x3_pipe.h", "wgrad_bf16.hip", "bf16_util.h"):
+            # launch-weighted mean over the template instances of the group (with / without the fused
+            # batch-norm-backward reduction, resident weights or not)
             recs = [rec for kname, rec in traffic.items()
-                    if isinstance(rec, dict) and (want + ">" in kname or want + "," in kname)]
+                    if isinstance(rec, dict) and any(t in kname for t in trace_names.get(name, (name,)))]
             if recs:
                 n = sum(r["launches"] for r in recs)
                 out["roofline"]["traffic"] = round(sum(r["traffic_bytes_per_launch"] * r["launches"] for r in recs) / n)

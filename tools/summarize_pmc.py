@@ -37,7 +37,7 @@ def main():
     # the kernel sources these counters were collected on (bench.py reports the traffic only for this build)
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import bench
-    out["_source_hash"] = bench.source_hash("conv_bf16.hip", "wgrad_bf16.hip", "bf16_util.h")
+    out["_source_hash"] = bench.source_hash("conv_bf16.hip", "conv3x3_pipe.h", "wgrad_bf16.hip", "bf16_util.h")
     json.dump(out, open(sys.argv[3], "w"), indent=1)
 
 

@@ -49,6 +49,7 @@ struct Args {
   int tilesX, tilesY;
   int units;            // N * tilesY * tilesX
   int co_blocks;        // CoP / 64
+  int xcd_order;        // 1: renumber the workgroups per XCD (needs gridDim.x % (8 * co_blocks) == 0)
   int co_valid;
   int accumulate;
   // BRED: the output is the gradient of a BN + ReLU layer's output; bz = that layer's pre-BN tensor,
@@ -127,7 +128,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pipe_kernel(const Args a) {
   const int ph = wave & 3, cw = wave >> 2;
   const int l15 = lane & 15, kp = lane >> 4;
 
-  const int cob = blockIdx.x % a.co_blocks, wgi = blockIdx.x / a.co_blocks, nwg = gridDim.x / a.co_blocks;
+  // Workgroup ids are dealt to the 8 XCDs (each with an L2 of its own) in turn.  Renumbered so that an XCD's
+  // workgroups are consecutive, the channel blocks of one tile sequence -- which read the same input -- and the
+  // neighbouring sequences -- which share halos -- sit on one XCD and fetch that input into one L2 once.
+  int bid = blockIdx.x;
+  if (a.xcd_order) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);
+  const int cob = bid % a.co_blocks, wgi = bid / a.co_blocks, nwg = gridDim.x / a.co_blocks;
   const int co0 = cob * 64;
   const int my_units = wgi < a.units ? (a.units - wgi + nwg - 1) / nwg : 0;
   if (my_units == 0) return;

@@ -512,6 +512,8 @@ int launch_pipe_from(const ConvArgs &c, hipStream_t s) {
   a.accumulate = c.accumulate;
   a.bz = c.bz; a.bz_ld = c.bz_ld; a.bcf = c.bcf; a.bred_c0 = c.bred_c0; a.affine = c.affine;
   const int grid = pipe::plan_grid(c.N, c.Ho, c.Wo, c.CoP);
+  static const bool xcd_off = getenv("UNET_LAB_NO_XCD_ORDER") != nullptr;  // laboratory switch (same results either way)
+  a.xcd_order = (!xcd_off && grid % (8 * a.co_blocks) == 0) ? 1 : 0;
   if (c.affine) return launch_pipe_ws<pipe::EPI_AFF>(a, grid, s);
   if (c.bz) return launch_pipe_ws<pipe::EPI_BRED>(a, grid, s);
   if (c.accumulate) return launch_pipe_ws<pipe::EPI_ACC>(a, grid, s);
