@@ -100,7 +100,8 @@ template <int TW, int MB>
 __global__ __launch_bounds__(256) void conv3x3_fwd_mfma_f32_kernel(const float *__restrict__ Wt,
                                                                    const float *__restrict__ X,
                                                                    float *__restrict__ Y, int Ci, int Co, int H,
-                                                                   int W, int tilesW, int splits, int ci_per_split) {
+                                                                   int W, int tilesW, int splits, int ci_per_split,
+                                                                   int Hi, int Wi, int pad) {
   constexpr int TH = 256 / TW;                  // tile rows
   constexpr int PR = TH + 2, PC = TW + 2;       // patch rows / columns
   constexpr int PITCH = TW == 32 ? 36 : 48;     // floats; 48 = 16 mod 32
@@ -130,9 +131,9 @@ __global__ __launch_bounds__(256) void conv3x3_fwd_mfma_f32_kernel(const float *
     __syncthreads();
     for (int e = tid; e < M_CIB * PR * PC; e += 256) {
       const int ci = e / (PR * PC), r = e - ci * PR * PC, ph = r / PC, pw = r - ph * PC;
-      const int ih = th0 - 1 + ph, iw = tw0 - 1 + pw;
+      const int ih = th0 - pad + ph, iw = tw0 - pad + pw;  // pad 1: same size; pad 0: the unpadded convolution
       float v = 0.f;
-      if (ci0 + ci < ci_end && ih >= 0 && ih < H && iw >= 0 && iw < W) v = X[((n * Ci + ci0 + ci) * H + ih) * W + iw];
+      if (ci0 + ci < ci_end && ih >= 0 && ih < Hi && iw >= 0 && iw < Wi) v = X[((n * Ci + ci0 + ci) * Hi + ih) * Wi + iw];
       patch[ci][ph][pw] = v;
     }
     for (int e = tid; e < M_CIB * COB * 9; e += 256) {  // global order (ci, co, tap): contiguous runs of COB * 9 floats
@@ -510,7 +511,7 @@ int unet_convolve_f32(const float *weights, const float *inputs, float *activati
                           stride, lds);
   const double flops = 2.0 * N * Co * Ho * Wo * (double)Ci * k * k;
   ProfScope prof(PROF_CONV_FWD_F32, flops, 4.0 * ((double)N * Ci * Hi * Wi + (double)N * Co * Ho * Wo), as_stream(s));
-  if (k == 3 && pad == 1 && stride == 1 && Co >= 16 && Wo >= 8 && Ho >= 4) {
+  if (k == 3 && pad <= 1 && stride == 1 && Co >= 16 && Wo >= 8 && Ho >= 4) {
     // matrix-core kernel: 8 x 32 pixel tiles for wide images, 16 x 16 otherwise; 64 output channels per
     // workgroup, 32 when that is needed to give every CU a workgroup
     const bool wide = Wo >= 32;
@@ -539,13 +540,13 @@ int unet_convolve_f32(const float *weights, const float *inputs, float *activati
     }
     dim3 g((unsigned)(tW * tH), (unsigned)cob, (unsigned)(N * splits));
     if (wide && two)
-      hipLaunchKernelGGL((conv3x3_fwd_mfma_f32_kernel<32, 2>), g, dim3(256), 0, as_stream(s), weights, inputs, dst, Ci, Co, Ho, Wo, tW, splits, ci_per_split);
+      hipLaunchKernelGGL((conv3x3_fwd_mfma_f32_kernel<32, 2>), g, dim3(256), 0, as_stream(s), weights, inputs, dst, Ci, Co, Ho, Wo, tW, splits, ci_per_split, Hi, Wi, pad);
     else if (wide)
-      hipLaunchKernelGGL((conv3x3_fwd_mfma_f32_kernel<32, 1>), g, dim3(256), 0, as_stream(s), weights, inputs, dst, Ci, Co, Ho, Wo, tW, splits, ci_per_split);
+      hipLaunchKernelGGL((conv3x3_fwd_mfma_f32_kernel<32, 1>), g, dim3(256), 0, as_stream(s), weights, inputs, dst, Ci, Co, Ho, Wo, tW, splits, ci_per_split, Hi, Wi, pad);
     else if (two)
-      hipLaunchKernelGGL((conv3x3_fwd_mfma_f32_kernel<16, 2>), g, dim3(256), 0, as_stream(s), weights, inputs, dst, Ci, Co, Ho, Wo, tW, splits, ci_per_split);
+      hipLaunchKernelGGL((conv3x3_fwd_mfma_f32_kernel<16, 2>), g, dim3(256), 0, as_stream(s), weights, inputs, dst, Ci, Co, Ho, Wo, tW, splits, ci_per_split, Hi, Wi, pad);
     else
-      hipLaunchKernelGGL((conv3x3_fwd_mfma_f32_kernel<16, 1>), g, dim3(256), 0, as_stream(s), weights, inputs, dst, Ci, Co, Ho, Wo, tW, splits, ci_per_split);
+      hipLaunchKernelGGL((conv3x3_fwd_mfma_f32_kernel<16, 1>), g, dim3(256), 0, as_stream(s), weights, inputs, dst, Ci, Co, Ho, Wo, tW, splits, ci_per_split, Hi, Wi, pad);
     UNET_LAUNCH_CHECK("conv3x3_fwd_mfma_f32_kernel");
     if (splits > 1) {
       hipLaunchKernelGGL(conv_split_reduce_f32_kernel, dim3(ew_grid(total)), dim3(256), 0, as_stream(s), (const float *)dst,
