@@ -328,6 +328,11 @@ int unet_difference_loss_backward_f32(const float *mask, const float *y, float *
 int unet_softmax_xent_f32(const float *logits, const int32_t *target, float *dlogits,
                           float *loss_out, int batch_size, int num_classes, int H, int W,
                           unet_stream_t stream);
+/* Helpers of the engine's cross-entropy loss (no counterpart in the reference): class indices handed over as
+ * floats -> int32 (rounded to nearest); out[n][pixel] = arg max over the C channels of x[n][:][pixel] (first
+ * on ties), as a float. */
+int unet_f32_to_i32(const float *in, int32_t *out, int64_t n, unet_stream_t stream);
+int unet_argmax_channels_f32(const float *x, float *out, int batch_size, int num_classes, int64_t HxW, unet_stream_t stream);
 
 /* ---- optimiser and small ops (cuda_lib.h:29-30, 245-259) ----------------- */
 

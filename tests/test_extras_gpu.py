@@ -192,3 +192,41 @@ def test_nonfinite_gradient_watch(oracle):
     with pytest.raises(RuntimeError, match="first seen at optimizer step 3"):
         net.train_step(x, m, 1e-3, True)
     assert net.nonfinite_step() == 3
+
+
+def test_cross_entropy_loss_in_the_engine():
+    """LossFunction.CROSS_ENTROPY_LOSS (not in the reference, whose SOFTMAX is an enum value only): a final layer
+    with several channels and the SOFTMAX activation gives logits, masks hold class indices; loss, gradients and a
+    few Adam steps against the PyTorch float64 oracle (F.cross_entropy), class map from infer()."""
+    import neural_net as nn
+    import torch.nn.functional as F
+    classes = 4
+    graph = torch_ref.main_py_graph(16, 24, 3, 4)
+    kind, shape, parents, _ = graph[-1]
+    graph[-1] = (kind, shape[:3] + [classes] + shape[4:], parents, "logits")
+    descs = torch_ref.to_layer_descs(nn, graph[:-1])
+    descs.append(nn.LayerDesc(nn.LayerType.CONV_LAYER, graph[-1][1], parents, nn.ActivationType.SOFTMAX))
+    net = nn.NeuralNet()
+    net.set_seed(4)
+    net.create(descs, nn.LossFunction.CROSS_ENTROPY_LOSS)
+    assert net.compute_dtype() == "f32"
+    rng = np.random.default_rng(10)
+    x = rng.standard_normal((3, 3, 16, 24)).astype(np.float32)
+    labels = rng.integers(0, classes, (3, 16, 24)).astype(np.float32)
+    p0 = net.get_parameters()
+    loss = net.train_step(x, labels, 1e-2, False)
+    g = net.get_gradients().astype(np.float64)
+    params = torch_ref.split_params(graph, p0)
+    acts = torch_ref.forward(graph, params, torch.from_numpy(x).double(), training=True)
+    ref = F.cross_entropy(acts[-1], torch.from_numpy(labels).long())
+    ref.backward()
+    ref_g = torch_ref.flat_grads(graph, params)
+    assert abs(loss - ref.item()) <= 1e-4 * ref.item()
+    assert np.linalg.norm(g - ref_g) <= 1e-3 * np.linalg.norm(ref_g), np.linalg.norm(g - ref_g) / np.linalg.norm(ref_g)
+    for _ in range(30):
+        last = net.train_step(x, labels, 2e-2, True)
+    assert last < 0.7 * loss
+    net.train(x, labels, 1e-3, 1, 2)
+    assert 0 < net.last_epoch_loss() < loss
+    cls = net.infer(x[0])
+    assert cls.shape == (1, 16, 24) and set(np.unique(cls)).issubset(set(range(classes)))

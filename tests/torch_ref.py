@@ -375,6 +375,8 @@ def forward(graph, params, x, training=True, running=None, emulate_bf16=False, n
                 pre.append(y.detach())
             if act == "sigmoid":
                 y = torch.sigmoid(y)
+            elif act == "logits":      # the final layer under the cross-entropy loss: no activation
+                pass
             elif act == "tanh" and kind == "conv":
                 y = torch.tanh(y)
             elif isinstance(act, str) and act.startswith("leaky:") and kind == "conv":

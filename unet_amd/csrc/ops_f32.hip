@@ -159,6 +159,29 @@ __global__ __launch_bounds__(256) void has_nan_kernel(const float *x, i64 n, int
     bad |= (x[i] != x[i]);
   if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
 }
+__global__ __launch_bounds__(256) void f32_to_i32_kernel(const float *__restrict__ in, int32_t *__restrict__ out, i64 n) {
+  for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (i64)gridDim.x * blockDim.x)
+    out[i] = (int32_t)lrintf(in[i]);
+}
+// out[n][i] = index of the largest of x[n][0..C)[i] (first on ties), as a float
+__global__ __launch_bounds__(256) void argmax_channels_kernel(const float *__restrict__ x, float *__restrict__ out, int N,
+                                                              int C, i64 HW) {
+  const i64 total = (i64)N * HW;
+  for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (i64)gridDim.x * blockDim.x) {
+    const i64 n = i / HW, p = i - n * HW;
+    const float *xp = x + n * C * HW + p;
+    float best = xp[0];
+    int arg = 0;
+    for (int c = 1; c < C; ++c) {
+      const float v = xp[(i64)c * HW];
+      if (v > best) {
+        best = v;
+        arg = c;
+      }
+    }
+    out[i] = (float)arg;
+  }
+}
 // *flag <- value if *flag was 0 and some x[i] is NaN or +-Inf
 __global__ __launch_bounds__(256) void nonfinite_flag_kernel(const float *__restrict__ x, i64 n, int *flag, int value) {
   int bad = 0;
@@ -592,6 +615,18 @@ int unet_tanh_f32(const float *inputs, float *activations, int64_t n, unet_strea
 int unet_tanh_backward_f32(const float *grad_activations, const float *activations, float *grad_inputs, int64_t n,
                            unet_stream_t s) {
   return launch_ew2(grad_activations, activations, grad_inputs, n, TanhBwdF(), s, "unet_tanh_backward_f32");
+}
+int unet_f32_to_i32(const float *in, int32_t *out, int64_t n, unet_stream_t s) {
+  UNET_REQUIRE(in && out && n > 0, "unet_f32_to_i32: bad argument");
+  hipLaunchKernelGGL(f32_to_i32_kernel, dim3(ew_grid(n)), dim3(256), 0, as_stream(s), in, out, (i64)n);
+  UNET_LAUNCH_CHECK("f32_to_i32_kernel");
+  return UNET_OK;
+}
+int unet_argmax_channels_f32(const float *x, float *out, int N, int C, int64_t HW, unet_stream_t s) {
+  UNET_REQUIRE(x && out && N > 0 && C > 0 && HW > 0, "unet_argmax_channels_f32: bad argument");
+  hipLaunchKernelGGL(argmax_channels_kernel, dim3(ew_grid((i64)N * HW)), dim3(256), 0, as_stream(s), x, out, N, C, (i64)HW);
+  UNET_LAUNCH_CHECK("argmax_channels_kernel");
+  return UNET_OK;
 }
 int unet_add_b_to_a_f32(float *a, const float *b, int64_t n, unet_stream_t s) {
   return launch_ew2(a, b, a, n, AddF(), s, "unet_add_b_to_a_f32");

@@ -98,7 +98,10 @@ class NN {
           else
             batch_sq += s[0];
         }
-        if (!is_dice) total += 0.5 * batch_sq / ((double)cur * f.out_h * f.out_w);
+        if (net_.loss() == LossFunction::kCrossEntropyLoss)
+          total += lv[3 * (size_t)batch_size * b];  // the batch's mean cross-entropy
+        else if (!is_dice)
+          total += 0.5 * batch_sq / ((double)cur * f.out_h * f.out_w);
       }
       const double avg_loss = is_dice ? 1.0 - total / (double)N : total / (double)nb;
       last_epoch_loss_ = (float)avg_loss;
@@ -108,7 +111,7 @@ class NN {
         if (is_dice)
           std::cout << "average dice score: " << total / (double)N << std::endl;
         else
-          std::cout << "average dice score: n/a (difference loss)" << std::endl;
+          std::cout << "average dice score: n/a (not the Dice loss)" << std::endl;
         std::cout << "images/s: " << (double)N / secs << std::endl;
       }
     }
@@ -162,6 +165,11 @@ class NN {
     check_input(ii.shape[0], ii.shape[1], ii.shape[2]);
     const unet::Node &f = net_.nodes()[net_.final_layer()];
     run_forward(static_cast<const float *>(ii.ptr), 1, true);
+    if (net_.loss() == LossFunction::kCrossEntropyLoss) {  // the class map: arg max over the logits, [1, H, W]
+      py::array_t<float> cls({(py::ssize_t)1, (py::ssize_t)f.out_h, (py::ssize_t)f.out_w});
+      net_.class_map_to_host(cls.mutable_data(), 1);
+      return cls;
+    }
     UNET_CALL(unet_threshold_f32(const_cast<float *>(f.act.f32()), 0.5f, f.out_elems(), net_.stream()));
     py::array_t<float> ret({(py::ssize_t)f.out_c, (py::ssize_t)f.out_h, (py::ssize_t)f.out_w});
     net_.copy_output_to_host(net_.final_layer(), ret.mutable_data(), 1);
@@ -174,6 +182,8 @@ class NN {
     if (ii.ndim != 3) throw std::runtime_error("Only accepting single images");
     check_input(ii.shape[0], ii.shape[1], ii.shape[2]);
     const unet::Node &f = net_.nodes()[net_.final_layer()];
+    if (net_.loss() == LossFunction::kCrossEntropyLoss)
+      throw std::runtime_error("test() returns a Dice score, which a class map does not have; use infer()");
     const py::ssize_t mh = mi.ndim >= 2 ? mi.shape[mi.ndim - 2] : -1, mw = mi.ndim >= 2 ? mi.shape[mi.ndim - 1] : -1;
     if (mh != f.out_h || mw != f.out_w || mi.size != (py::ssize_t)f.out_h * f.out_w)
       throw std::runtime_error("Mask dimensions do not match image dimensions");
@@ -489,6 +499,7 @@ PYBIND11_MODULE(neural_net, m) {
   py::enum_<LossFunction>(m, "LossFunction")
       .value("DICE_LOSS", LossFunction::kDiceLoss)
       .value("DIFFERENCE_LOSS", LossFunction::kDifferenceLoss)
+      .value("CROSS_ENTROPY_LOSS", LossFunction::kCrossEntropyLoss)
       .export_values();
 
   py::enum_<Layer_type>(m, "LayerType")

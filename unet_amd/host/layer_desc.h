@@ -19,6 +19,10 @@ enum Activation_type { ReLU, SOFTMAX, NONE, TANH, SIGMOID, LEAKY_ReLU };
 enum class LossFunction {
   kDiceLoss,
   kDifferenceLoss,
+  // not in the reference (neural_net.h:18 has the two above): softmax cross-entropy over the channels of the
+  // final layer, masks holding class indices; the final layer's SOFTMAX activation (layer.h:31, which the
+  // reference declares and runs as ReLU) is then the identity and the softmax lives in the loss
+  kCrossEntropyLoss,
 };
 
 // descriptor field orders (layer.h:426-432, 461-465, 580-584):

@@ -285,16 +285,26 @@ class Net {
   // Sums for the loss of the current forward output; fills loss_values_.
   void loss_forward_device(const float *masks, int batch) {
     Node &f = nodes_[final_];
-    if (loss_ == LossFunction::kDiceLoss)
+    if (loss_ == LossFunction::kDiceLoss) {
       UNET_CALL(unet_dice_sums_f32(masks, f.act.f32(), f.out_h, f.out_w, batch, loss_values_.f32(), stream_));
-    else
+    } else if (loss_ == LossFunction::kDifferenceLoss) {
       UNET_CALL(unet_difference_loss_sums_f32(masks, f.act.f32(), f.out_h, f.out_w, batch, loss_values_.f32(), stream_));
+    } else {
+      // cross-entropy: masks hold class indices; the loss (mean over the batch's pixels) goes to
+      // loss_values_[0] and its gradient with respect to the logits straight into the final layer's grad_out
+      const int64_t pixels = (int64_t)batch * f.out_h * f.out_w;
+      labels_.ensure(sizeof(int32_t) * (size_t)pixels);
+      UNET_CALL(unet_f32_to_i32(masks, static_cast<int32_t *>(labels_.raw()), pixels, stream_));
+      UNET_CALL(unet_softmax_xent_f32(f.act.f32(), static_cast<const int32_t *>(labels_.raw()), f.grad_out.f32(),
+                                      loss_values_.f32(), batch, f.out_c, f.out_h, f.out_w, stream_));
+    }
   }
 
   void backward_device(const float *images, const float *masks, int batch) {
     require_created();
     Node &f = nodes_[final_];
-    if (f.out_c != 1) throw std::runtime_error("the loss functions need a final layer with one output channel");
+    if (f.out_c != 1 && loss_ != LossFunction::kCrossEntropyLoss)
+      throw std::runtime_error("the loss functions need a final layer with one output channel");
     for (Node &n : nodes_) n.grad_seen = false;
     next_bucket_ = 0;
     if (comm_) UNET_CALL(unet_allreduce_wait(comm_, stream_));  // a reduction of the last step still in flight
@@ -303,10 +313,10 @@ class Net {
       // L = 1 - mean_n dice_n  =>  dL/dp = -(1/N) * 2(mD - I)/D^2
       UNET_CALL(unet_dice_loss_backward_f32(masks, f.act.f32(), loss_values_.f32(), f.grad_out.f32(), f.out_h,
                                             f.out_w, batch, -1.0f / (float)batch, stream_));
-    } else {
+    } else if (loss_ == LossFunction::kDifferenceLoss) {
       UNET_CALL(unet_difference_loss_backward_f32(masks, f.act.f32(), f.grad_out.f32(),
                                                   (int64_t)batch * f.out_h * f.out_w, stream_));
-    }
+    }  // cross-entropy: loss_forward_device has written the gradient
     f.grad_seen = true;
     if (use_bf16_)
       for (Node &n : nodes_) {
@@ -493,6 +503,10 @@ class Net {
     std::vector<float> lv(3 * (size_t)batch);
     UNET_CALL(unet_memcpy_d2h(lv.data(), loss_values_.raw(), sizeof(float) * lv.size(), 1, stream_));
     raise_if_nonfinite();
+    if (loss_ == LossFunction::kCrossEntropyLoss) {
+      if (dice_out) *dice_out = std::numeric_limits<float>::quiet_NaN();
+      return lv[0];
+    }
     if (loss_ == LossFunction::kDiceLoss) {
       float dice = 0.f;
       for (int i = 0; i < batch; ++i) dice += 2.0f * lv[3 * i] / (lv[3 * i + 1] + lv[3 * i + 2] + 1e-5f);
@@ -665,6 +679,14 @@ class Net {
     loss_values_.ensure(sizeof(float) * 3 * b);
     alloc_batch_ = batch;
   }
+  // cross-entropy networks: arg max over the final layer's channels of the last forward, [batch][H][W] floats
+  void class_map_to_host(float *dst, int batch) {
+    const Node &f = nodes_[final_];
+    const size_t n = (size_t)batch * f.out_h * f.out_w;
+    scratch_g1_.ensure(sizeof(float) * n);
+    UNET_CALL(unet_argmax_channels_f32(f.act.f32(), scratch_g1_.f32(), batch, f.out_c, (int64_t)f.out_h * f.out_w, stream_));
+    UNET_CALL(unet_memcpy_d2h(dst, scratch_g1_.raw(), sizeof(float) * n, 1, stream_));
+  }
   float *input_images_ptr() const { return in_images_.f32(); }
   float *input_masks_ptr() const { return in_masks_.f32(); }
 
@@ -832,9 +854,12 @@ class Net {
   // convolution layers); every other value -- NONE, the LayerDesc default that main.py:187-224 relies on,
   // included -- is ReLU, as in the reference (convolution_layer_functions.h:59-65,
   // upsampling_layer_functions.h:57-65).
-  static Activation_type effective_activation(const Node &n) {
+  // Under the cross-entropy loss the final layer's SOFTMAX is the identity here (returned as NONE): the
+  // softmax is part of the loss.
+  Activation_type effective_activation(const Node &n) const {
     if (n.type == CONV_LAYER && (n.activation == SIGMOID || n.activation == TANH || n.activation == LEAKY_ReLU))
       return n.activation;
+    if (loss_ == LossFunction::kCrossEntropyLoss && &n == &nodes_[final_]) return NONE;
     return ReLU;
   }
 
@@ -867,6 +892,7 @@ class Net {
           case SIGMOID: UNET_CALL(unet_sigmoid_f32(n.bn.f32(), n.act.f32(), out_n, stream_)); break;
           case TANH: UNET_CALL(unet_tanh_f32(n.bn.f32(), n.act.f32(), out_n, stream_)); break;
           case LEAKY_ReLU: UNET_CALL(unet_leaky_relu_f32(n.bn.f32(), n.act.f32(), out_n, n.leaky, stream_)); break;
+          case NONE: UNET_CALL(unet_memcpy_d2d(n.act.raw(), n.bn.raw(), sizeof(float) * (size_t)out_n, stream_)); break;
           default: UNET_CALL(unet_relu_f32(n.bn.f32(), n.act.f32(), out_n, stream_));
         }
         break;
@@ -920,6 +946,7 @@ class Net {
           case LEAKY_ReLU:
             UNET_CALL(unet_leaky_relu_backward_f32(n.grad_out.f32(), n.bn.f32(), g2, out_n, n.leaky, stream_));
             break;
+          case NONE: UNET_CALL(unet_memcpy_d2d(g2, n.grad_out.raw(), sizeof(float) * (size_t)out_n, stream_)); break;
           default: UNET_CALL(unet_relu_backward_f32(n.grad_out.f32(), n.bn.f32(), g2, out_n, stream_));
         }
         UNET_CALL(unet_batch_norm_backward_f32(g2, n.z.f32(), n.batch_stats.f32(), w + n.num_wb, g1, gw + n.num_wb,
@@ -1008,6 +1035,10 @@ class Net {
   // the activations: a layer feeding a CONCAT writes straight into its slice of
   // the concat buffer, so concat forward and backward move no data.
   bool plan_bf16(std::string &why) {
+    if (loss_ == LossFunction::kCrossEntropyLoss) {
+      why = "the cross-entropy loss runs on the fp32 kernels";
+      return false;
+    }
     for (Node &n : nodes_) {
       n.concat_child = -1;
       n.pool_child = -1;
@@ -1462,6 +1493,7 @@ class Net {
   DeviceBuffer params_, grads_, adam_;
   DeviceBuffer scratch_g1_, scratch_g2_, scratch_dx_;
   DeviceBuffer in_images_, in_masks_, loss_values_;
+  DeviceBuffer labels_;  // cross-entropy: the masks as int32 class indices
   int alloc_batch_ = 0;
   int step_count_ = 0;
   uint64_t seed_ = 0;
