@@ -148,6 +148,27 @@ def test_conv3x3_forward_dgrad_wgrad(G, capi, oracle, cfg):
     assert np.abs(got - ref).max() <= 1e-3 * np.abs(ref).max(), (np.abs(got - ref).max(), np.abs(ref).max())
 
 
+@pytest.mark.parametrize("cfg", [(3, 256, 256, 50, 70), (1, 512, 512, 64, 128), (2, 64, 192, 72, 80)])
+def test_conv3x3_wgrad_long_pixel_slices(G, capi, cfg):
+    """Weight gradient where one workgroup walks many 8 x 16 pixel chunks in a row (all three stage buffers of
+    its load pipeline get reused several times), with ragged image edges, across image boundaries, and with a
+    slice that ends before its last trip: against torch's fp32 convolution gradient on the CPU."""
+    n, ci, co, h, w = cfg
+    rng = np.random.default_rng(ci + co + h)
+    x = bf16_round(rng.standard_normal((n, ci, h, w)))
+    dy = bf16_round(rng.standard_normal((n, co, h, w)))
+    xt, dyt = to_nhwc(G, capi, x), to_nhwc(G, capi, dy)
+    gw = G.empty((ci * co * 9,))
+    capi.unet_conv3x3_wgrad_bf16(G.p(dyt), co, G.p(xt), ci, G.p(gw), n, h, w, ci, co, ci, co, None)
+    got = G.host(gw).reshape(ci, co, 3, 3)
+    ref = torch.nn.grad.conv2d_weight(torch.from_numpy(x), (co, ci, 3, 3), torch.from_numpy(dy), padding=1)
+    ref = ref.permute(1, 0, 2, 3).numpy()
+    assert np.abs(got - ref).max() <= 1e-3 * np.abs(ref).max(), (np.abs(got - ref).max(), np.abs(ref).max())
+    again = G.empty((ci * co * 9,))
+    capi.unet_conv3x3_wgrad_bf16(G.p(dyt), co, G.p(xt), ci, G.p(again), n, h, w, ci, co, ci, co, None)
+    np.testing.assert_array_equal(G.host(again).reshape(ci, co, 3, 3), got)
+
+
 def test_conv3x3_reads_channel_slices(G, capi, oracle):
     """Input and output tensors that are channel slices of wider buffers
     (pixel stride > channel count): the zero-copy concat layout."""

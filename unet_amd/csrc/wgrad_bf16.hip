@@ -11,6 +11,8 @@
 // This file is compiled with -mllvm -amdgpu-mfma-vgpr-form: the 9 accumulator tiles of a wave stay
 // in ordinary vector registers.  Without it the compiler copies all 144 accumulator registers
 // between the two halves of the register file on every pass of the pixel loop.
+#include <stdlib.h>
+
 #include "bf16_util.h"
 
 namespace {
@@ -201,6 +203,236 @@ __global__ __launch_bounds__(256, 1) void wgrad_mfma_kernel(const WgradArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------
+// The same weight gradient with the operands going memory -> LDS directly (buffer_load ... lds) two chunks
+// ahead of the MFMAs, one barrier per chunk.  wgrad_mfma_kernel above stages a chunk through registers
+// (load, MFMA loop, barrier, ds_write, barrier) with the next chunk's loads in flight only while one chunk is
+// computed -- about a microsecond, less than a memory round trip under load, with one wave per SIMD to hide it.
+// Same MFMA loop, same fragment values, same order of additions: the partial blocks are bit-identical.
+//
+// LDS image of a stage: pixel rows of 128 bytes (64 channels), dense; the 64-byte halves of a row are swapped
+// when bit 1 of the row index is set, so that the 4 rows x 64 bytes a transposing read touches per half wave
+// cover the 64 banks once (the register-staged kernel pads rows to 192 bytes instead, which a lane-linear
+// LDS load cannot produce).  The swap is applied to the SOURCE address: wave instruction i fills bytes
+// [1024 i, 1024 i + 1024), lane l's 16 bytes are row 8 i + l / 8, slot l % 8, and hold source piece
+// slot ^ (4 * ((row >> 1) & 1)).  Out-of-image pixels and absent channels address beyond the descriptor and
+// arrive as zeros.
+constexpr int DROW = 128;
+typedef __attribute__((address_space(3))) void *wg_lds_ptr_t;
+
+// One LDS load instruction: 64 lanes x 16 bytes from the buffer `rsrc` (lane offset `voffset`, beyond the
+// descriptor = zeros) to the 1 KiB of LDS at byte address `lds_addr`, lane-linear.  Issued as assembly and not
+// through the builtin: the compiler then does not know of an outstanding LDS write and does not put
+// s_waitcnt vmcnt(0) in front of the transposing LDS reads of the chunk being computed (it cannot tell that
+// they read another stage buffer) -- which would serialise the loads two chunks ahead with the MFMAs.  The
+// kernel counts its vector-memory operations itself (wg_wait_vmem_then_barrier).
+__device__ __forceinline__ void wg_lds_load_b128(i32x4 rsrc, unsigned lds_addr, unsigned voffset) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
+               :
+               : "s"(lds_addr), "v"(voffset), "s"(rsrc));
+}
+__device__ __forceinline__ i32x4 wg_make_rsrc(const void *base, unsigned bytes) {
+  const uint64_t b = (uint64_t)base;
+  return i32x4{(int)(unsigned)b, (int)(unsigned)(b >> 32), (int)bytes, 0x00020000};
+}
+
+template <int N>
+__device__ __forceinline__ void wg_wait_vmem_then_barrier() {
+  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+
+template <int TAPS, int STAGES>
+__global__ __launch_bounds__(256, 1) void wgrad_dma_kernel(const WgradArgs a) {
+  constexpr int XR = (TAPS == 9) ? 10 : 8, XC = (TAPS == 9) ? 18 : 16;
+  constexpr int XPIX = XR * XC;
+  constexpr int Z_INSTR = 16, X_INSTR = (TAPS == 9) ? 24 : 16;  // wave instructions of 8 pixel rows each
+  constexpr int PER_WAVE = (Z_INSTR + X_INSTR) / 4;               // every wave issues the same number
+  constexpr int Z_BYTES = Z_INSTR * 1024, STAGE = (Z_INSTR + X_INSTR) * 1024;
+  constexpr unsigned OOB = 0x80000000u;
+  extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];  // three stages
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int co0 = blockIdx.y * 64, ci0 = blockIdx.z * 64;
+  int split = blockIdx.x, phase = 0, dz_oy = a.dz_oy, dz_ox = a.dz_ox;
+  if (TAPS == 1 && a.phases > 1) {
+    phase = split & 3;
+    split >>= 2;
+    dz_oy = phase >> 1;
+    dz_ox = phase & 1;
+  }
+  const int wm = wave >> 1, wn = wave & 1;
+
+  f32x16 acc[TAPS];
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  // fragment addresses: logical (row, byte column) of wgrad_mfma_kernel, physical = row * 128 + (column ^ swap)
+  const int grp = lane >> 4, li = lane & 15, q = li >> 2, p = li & 3, h = grp >> 1;
+  const int z_col = (wm * 32 + 16 * (grp & 1) + 4 * p) * 2, x_col = (wn * 32 + 16 * (grp & 1) + 4 * p) * 2;
+  const int z_lane = (8 * h + q) * DROW + (z_col ^ (((q >> 1) & 1) << 6));  // base rows of dz are multiples of 16
+  int x_lane[4];  // by (first row of the fragment) & 3
+#pragma unroll
+  for (int v = 0; v < 4; ++v) x_lane[v] = (8 * h + q) * DROW + (x_col ^ ((((v + q) >> 1) & 1) << 6));
+
+  const int c_begin = split * a.chunks_per_split;
+  const int c_end = min(a.total_chunks, c_begin + a.chunks_per_split);
+  const int per_img = a.chunksX * a.chunksY;
+
+  // per-lane source plan of this wave's PER_WAVE instructions (fixed for the whole kernel): byte offset
+  // relative to the chunk origin and pixel column relative to the chunk's first.  A piece that does not exist
+  // (row beyond the halo box, channel beyond the tensor) gets a column that is never inside an image.
+  int rel[PER_WAVE], pxk[PER_WAVE];
+#pragma unroll
+  for (int k = 0; k < PER_WAVE; ++k) {
+    const int i = wave + 4 * k;
+    const bool is_z = k < Z_INSTR / 4;  // the same for all four waves: known at compile time
+    const int row = 8 * (is_z ? i : i - Z_INSTR) + (lane >> 3);
+    const int piece = (lane & 7) ^ (((row >> 1) & 1) << 2);
+    if (is_z) {
+      const int py = row >> 4, px = row & 15;
+      const bool ok = co0 + piece * 8 < a.z_c;
+      rel[k] = (((py * a.dz_s + dz_oy) * a.Wz + px * a.dz_s + dz_ox) * a.dz_ld + co0 + piece * 8) * 2;
+      pxk[k] = ok ? px : -(1 << 24);
+    } else {
+      const int py = row / XC - (TAPS == 9), px = row - (row / XC) * XC - (TAPS == 9);
+      const bool ok = row < XPIX && ci0 + piece * 8 < a.x_c;
+      rel[k] = ((py * a.W + px) * a.x_ld + ci0 + piece * 8) * 2;
+      pxk[k] = ok ? px : -(1 << 24);
+    }
+  }
+  const unsigned x_img_bytes = (unsigned)a.H * a.W * a.x_ld * 2u, z_img_bytes = (unsigned)a.Hz * a.Wz * a.dz_ld * 2u;
+
+  // The chunk whose loads are issued next: its image and chunk coordinates advance by one per call (no
+  // divisions in the loop).  Past the end of the slice the loads still go out, addressed beyond the
+  // descriptor (zeros into a stage buffer nobody reads): every trip of the main loop is the same straight
+  // line of code, which lets the compiler spread the address arithmetic between the MFMAs.
+  int i_chunk = c_begin, i_n = c_begin / per_img, i_cy = (c_begin - i_n * per_img) / a.chunksX,
+      i_cx = c_begin - i_n * per_img - i_cy * a.chunksX;
+  // plan_chunk() works out the addresses of the chunk to be issued next -- plain arithmetic, written after the
+  // MFMAs of a trip so that the compiler spreads it between them; issue_chunk() is then ten load instructions.
+  unsigned vo[PER_WAVE];
+  i32x4 xrs, zrs;
+  auto plan_chunk = [&]() {
+    // Only the pixel column is tested here.  A pixel row above the image makes the offset negative, one below
+    // it puts the offset past the image: both are beyond the descriptor (which covers one image of less than
+    // 2^30 bytes) and read as zeros.  A chunk past the end of the slice gets a column origin far outside.
+    const int y0 = i_cy * 8, x0 = i_cx * 16;
+    const int x0_test = (i_chunk < c_end) ? x0 : -(1 << 24);
+    xrs = wg_make_rsrc(a.x + (i64)i_n * a.H * a.W * a.x_ld, x_img_bytes);
+    zrs = wg_make_rsrc(a.dz + (i64)i_n * a.Hz * a.Wz * a.dz_ld, z_img_bytes);
+    const int x_org = (y0 * a.W + x0) * a.x_ld * 2;
+    const int z_org = (y0 * a.dz_s * a.Wz + x0 * a.dz_s) * a.dz_ld * 2;
+#pragma unroll
+    for (int k = 0; k < PER_WAVE; ++k) {
+      const unsigned off = (unsigned)((k < Z_INSTR / 4 ? z_org : x_org) + rel[k]);
+      vo[k] = ((unsigned)(x0_test + pxk[k]) < (unsigned)a.W) ? off : OOB;
+    }
+    ++i_chunk;
+    const bool row_end = ++i_cx == a.chunksX;
+    i_cx = row_end ? 0 : i_cx;
+    i_cy += row_end;
+    const bool img_end = i_cy == a.chunksY;
+    i_cy = img_end ? 0 : i_cy;
+    i_n += img_end;
+  };
+  auto issue_chunk = [&](unsigned char *dst) {
+    const unsigned dst_addr = (unsigned)(uintptr_t)(wg_lds_ptr_t)dst + wave * 1024;
+#pragma unroll
+    for (int k = 0; k < PER_WAVE; ++k)  // instruction wave + 4 k: dz for k < 4 whatever the wave
+      wg_lds_load_b128(k < Z_INSTR / 4 ? zrs : xrs, dst_addr + k * 4096, vo[k]);
+  };
+
+  static_assert(STAGES == 3 && TAPS == 9, "the loop below keeps two chunks of a 3x3 filter in flight");
+  // One wave per SIMD: nobody else's MFMAs cover this wave's LDS latency, so the fragments of halo row r + 1
+  // are read while the MFMAs of row r run (four dz fragments and two sets of x fragments live), and that
+  // pipeline does not stop at a chunk's end.  The one barrier of a chunk stands in front of its last halo
+  // row: by then a wave has read all of the chunk's fragments and its own pieces of the next chunk have
+  // landed (the chunk after that may be in flight); behind the barrier that holds for every wave, so the
+  // next chunk's first row can be read and the loads three chunks ahead can overwrite this chunk.
+  plan_chunk();
+  issue_chunk(lds);
+  plan_chunk();
+  issue_chunk(lds + STAGE);
+  plan_chunk();
+  bf16x8 aw[4], bq[2][3];
+  auto read_row = [&](const unsigned char *stage, int rn) {
+    if (rn < 8) {
+      const unsigned char *zp = stage + rn * 16 * DROW + z_lane;
+      aw[rn & 3] = tr_read_pair(zp, zp + 4 * DROW);
+    }
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+      const unsigned char *xp = stage + Z_BYTES + (rn * XC + kw) * DROW + x_lane[(rn * XC + kw) & 3];
+      bq[rn & 1][kw] = tr_read_pair(xp, xp + 4 * DROW);
+    }
+  };
+  wg_wait_vmem_then_barrier<PER_WAVE>();
+  issue_chunk(lds + 2 * STAGE);
+  plan_chunk();
+  read_row(lds, 0);
+  int buf = 0;
+  for (int chunk = c_begin; chunk < c_end; ++chunk) {
+    const unsigned char *cur = lds + buf * STAGE;
+    const int nb = buf == 2 ? 0 : buf + 1;
+    auto mfma_row = [&](int r) {
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+          const int ks = r - kh;
+          if (ks >= 0 && ks < 8)
+            acc[kh * 3 + kw] =
+                __builtin_amdgcn_mfma_f32_32x32x16_bf16(aw[ks & 3], bq[r & 1][kw], acc[kh * 3 + kw], 0, 0, 0);
+        }
+    };
+#pragma unroll
+    for (int r = 0; r < 9; ++r) {
+      read_row(cur, r + 1);
+      mfma_row(r);
+    }
+    // the order above, pinned for the scheduler: reads of row r + 1, then the MFMAs of row r
+#pragma unroll
+    for (int r = 0; r < 9; ++r) {
+      if (r + 1 >= 8)
+        __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+      else
+        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+      if (r == 0) __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+      if (r == 1 || r == 8) __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+      if (r >= 2 && r < 8) __builtin_amdgcn_sched_group_barrier(0x008, 9, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);  // the barrier stays behind the MFMAs of row 8, which cover the reads of row 9
+    wg_wait_vmem_then_barrier<PER_WAVE>();
+    read_row(lds + nb * STAGE, 0);
+    issue_chunk(lds + buf * STAGE);  // this chunk's own buffer: all of its fragments are in registers
+    mfma_row(9);
+    plan_chunk();
+    __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+    buf = nb;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the loads issued past the end of the slice
+  const int slices = (TAPS == 1 && a.phases > 1) ? a.phases : TAPS;
+  const auto prs = __builtin_amdgcn_make_buffer_rsrc(a.partial + ((i64)split * slices + phase) * a.CoP * a.CiP, 0,
+                                                     (unsigned)TAPS * a.CoP * a.CiP * 4u, 0x00020000);
+  const unsigned row_bytes = (unsigned)a.CiP * 4u;
+  unsigned off = ((unsigned)(co0 + wm * 32 + 4 * (lane >> 5)) * a.CiP + ci0 + wn * 32 + (lane & 31)) * 4u;
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t) {
+    unsigned o = off;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float v = acc[t][r];
+      __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(v), prs, o, 0, 0);
+      o += ((r & 3) == 3) ? 5 * row_bytes : row_bytes;
+    }
+    off += (unsigned)a.CoP * row_bytes;
+  }
+}
+
 // grad[(ci*Co + co)*taps_total + tap_base + t] = sum_split partial[split][t][co][ci]
 // A workgroup owns 32 consecutive ci of one (t, co) row; its 8 groups of 32 lanes each add every
 // eighth split slice (128-byte coalesced reads), then the 8 partial sums are added in a fixed order.
@@ -319,6 +551,9 @@ static int run_wgrad(int taps, int phases, const WgradArgs &base, float *grad, i
   if (rc) return rc;
   a.partial = (float *)ws;
   const size_t lds = (size_t)128 * WP + (size_t)(taps == 9 ? 180 : 128) * WP;
+  // laboratory switch: 0 = register-staged kernel, 1 = direct-to-LDS, 2 = direct-to-LDS with prefetched fragments
+  static const int dma_env = getenv("UNET_LAB_WGRAD_DMA") ? atoi(getenv("UNET_LAB_WGRAD_DMA")) : 2;
+  const size_t lds_dma = (size_t)3 * 40 * 1024;
   static bool attr_set[64] = {};
   int dev = 0;
   UNET_HIP_TRY(hipGetDevice(&dev));
@@ -327,6 +562,8 @@ static int run_wgrad(int taps, int phases, const WgradArgs &base, float *grad, i
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)((128 + 180) * WP)));
     UNET_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&wgrad_mfma_kernel<1>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)((128 + 128) * WP)));
+    UNET_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&wgrad_dma_kernel<9, 3>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 40 * 1024));
     attr_set[dev & 63] = true;
   }
   dim3 grid((unsigned)(splits * phases), (unsigned)(a.CoP / 64), (unsigned)(a.CiP / 64));
@@ -334,7 +571,12 @@ static int run_wgrad(int taps, int phases, const WgradArgs &base, float *grad, i
   {
     ProfScope prof(taps == 9 ? PROF_CONV_WGRAD_BF16 : PROF_TCONV_WGRAD_BF16, flops,
                    2.0 * a.N * a.H * a.W * ((double)a.x_c * phases + (double)a.z_c * phases) + partial_bytes, s);
-    if (taps == 9)
+    // the direct-to-LDS kernel relies on one image staying below 2^30 bytes (see plan_chunk)
+    const bool small_images = (i64)a.H * a.W * a.x_ld * 2 < (1ll << 30) && (i64)a.Hz * a.Wz * a.dz_ld * 2 < (1ll << 30);
+    const int dma = small_images ? dma_env : 0;
+    if (taps == 9 && dma)
+      hipLaunchKernelGGL((wgrad_dma_kernel<9, 3>), grid, dim3(256), lds_dma, s, a);
+    else if (taps == 9)
       hipLaunchKernelGGL(wgrad_mfma_kernel<9>, grid, dim3(256), lds, s, a);
     else
       hipLaunchKernelGGL(wgrad_mfma_kernel<1>, grid, dim3(256), lds, s, a);
