@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Writes the weight gradients of a few layer shapes (3x3 and 2x2-transposed) to an .npz: run once with
-UNET_LAB_WGRAD_STAGED=1 and once without, then compare the two files bit for bit (tools/wgrad_dump.py a.npz b.npz)."""
+UNET_LAB_WGRAD_DMA=0 (the register-staged kernel) and once without, then compare the two files bit for bit (tools/wgrad_dump.py a.npz b.npz)."""
 import os
 import sys
 import time
