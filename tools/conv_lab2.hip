@@ -8,6 +8,9 @@
 #include <algorithm>
 #include <vector>
 
+// the laboratory's copy of the kernel gets symbols of its own: with the library's names the loader binds both
+// to one definition and the build switches of this file (PIPE_LAB_ABLATE) would not be what runs
+#define pipe pipe_lab
 #include "../unet_amd/csrc/conv3x3_pipe.h"
 
 #define CK(x)                                                                            \
@@ -118,6 +121,7 @@ int main(int argc, char **argv) {
     a.tilesX = (s.H + pipe::TW - 1) / pipe::TW; a.tilesY = (s.H + pipe::TH - 1) / pipe::TH;
     a.units = N * a.tilesX * a.tilesY; a.co_blocks = s.Co / 64; a.co_valid = s.Co;
     const int grid = pipe::plan_grid(N, s.H, s.H, s.Co, wgs);
+    a.xcd_order = (grid % (8 * a.co_blocks) == 0 && !getenv("LAB_NO_XCD")) ? 1 : 0;
     const bool ws = a.nk <= pipe::MAX_WS_CHUNKS;
     auto launch = [&] {
       if (ws)

@@ -20,7 +20,8 @@
 #pragma once
 #include "bf16_util.h"
 #ifndef PIPE_LAB_ABLATE
-#define PIPE_LAB_ABLATE 0  // laboratory builds only: 1 = no output stores, 2 = no MFMAs
+#define PIPE_LAB_ABLATE 0  // laboratory builds only: 1 = no output stores, 2 = no MFMAs, 3 = no halo loads,
+                            // 4 = no operand loads at all after the first stage (matrix cores + LDS reads only)
 #endif
 
 namespace pipe {
@@ -285,7 +286,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pipe_kernel(const Args a) {
         wait_vmem_then_barrier<0>();
       if (s + 1 < S) {
         const int it2 = (kc + 1 < nk) ? it : it + 1, kc2 = (kc + 1 < nk) ? kc + 1 : 0;
+#if PIPE_LAB_ABLATE == 4
+        if (a.N < 0)
+#endif
         if (!WS) issue_weights(kc2, weight_buf(s + 1, kc2));
+#if PIPE_LAB_ABLATE == 3 || PIPE_LAB_ABLATE == 4
+        if (a.N < 0)
+#endif
         issue_halo(it2, kc2, halo_buf(s + 1));
       }
       if ((BRED || EPI == EPI_ACC) && kc == nk - 1) {
@@ -364,6 +371,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pipe_kernel(const Args a) {
         hw[m] = __builtin_bit_cast(u32x2, h);
         rv[m] = __builtin_convertvector(h, f32x4);
       }
+#if PIPE_LAB_ABLATE == 1
+      if (a.N < 0)
+#endif
       __builtin_amdgcn_raw_buffer_store_b128(swap16(hw), ors, ooff[q], 0, 0);
       if (STATS) {
 #pragma unroll

@@ -476,46 +476,53 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restri
   }
 }
 
-// Same reduction for layers with many outputs and few split slices: a workgroup owns a
-// 32(ci) x 8(co) x taps box, reads it with 128-byte coalesced rows, transposes through LDS and
-// writes runs of 8*taps consecutive floats of the reference layout.
+// Same reduction for layers with many outputs and few split slices: a workgroup of 32 x COB threads
+// (COB = blockDim.x / 32 = 4 or 8) owns a 32(ci) x COB(co) x TAPS box, reads it with 128-byte coalesced rows --
+// all taps of four slices requested before the first addition, so a thread has 4 * TAPS loads in flight and a
+// layer with four slices costs one memory round trip instead of nine -- transposes through LDS and writes runs
+// of COB * TAPS consecutive floats of the reference layout.  The additions run in slice order.
+template <int TAPS>
 __global__ __launch_bounds__(256) void wgrad_reduce_tile_kernel(const float *__restrict__ partial,
-                                                                float *__restrict__ grad, int splits, int taps,
-                                                                int CoP, int CiP, int Co, int Ci, int taps_total,
-                                                                int tap_base) {
-  __shared__ float tile[32][8 * 9 + 1];
-  const int lane32 = threadIdx.x & 31, grp = threadIdx.x >> 5;
-  const int ci0 = blockIdx.x * 32, co0 = blockIdx.y * 8;
+                                                                float *__restrict__ grad, int splits, int CoP,
+                                                                int CiP, int Co, int Ci) {
+  __shared__ float tile[32][8 * TAPS + 1];
+  const int lane32 = threadIdx.x & 31, grp = threadIdx.x >> 5, COB = blockDim.x >> 5;
+  const int ci0 = blockIdx.x * 32, co0 = blockIdx.y * COB;
   const int ci = ci0 + lane32, co = co0 + grp;
-  const i64 slice = (i64)taps * CoP * CiP;
-  for (int t = 0; t < taps; ++t) {
-    float s = 0.f;
-    if (ci < Ci && co < Co) {
-      const float *p = partial + ((i64)t * CoP + co) * CiP + ci;
-      int k = 0;
-      for (; k + 7 < splits; k += 8) {
-        float v[8];
+  const i64 tap_stride = (i64)CoP * CiP, slice = (i64)TAPS * tap_stride;
+  float s[TAPS];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = p[(k + u) * slice];
+  for (int t = 0; t < TAPS; ++t) s[t] = 0.f;
+  if (ci < Ci && co < Co) {
+    const float *p = partial + (i64)co * CiP + ci;
+    int k = 0;
+    for (; k + 3 < splits; k += 4) {
+      float v[4][TAPS];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) s += v[u];
-      }
-      for (; k + 1 < splits; k += 2) {
-        const float v0 = p[k * slice], v1 = p[(k + 1) * slice];
-        s += v0;
-        s += v1;
-      }
-      for (; k < splits; ++k) s += p[k * slice];
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t) v[u][t] = p[(k + u) * slice + t * tap_stride];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t) s[t] += v[u][t];
     }
-    tile[lane32][grp * taps + t] = s;
+    for (; k < splits; ++k) {
+      float v[TAPS];
+#pragma unroll
+      for (int t = 0; t < TAPS; ++t) v[t] = p[k * slice + t * tap_stride];
+#pragma unroll
+      for (int t = 0; t < TAPS; ++t) s[t] += v[t];
+    }
   }
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t) tile[lane32][grp * TAPS + t] = s[t];
   __syncthreads();
-  const int run = 8 * taps;
-  for (int idx = threadIdx.x; idx < 32 * run; idx += 256) {
+  const int run = COB * TAPS;
+  for (int idx = threadIdx.x; idx < 32 * run; idx += blockDim.x) {
     const int cl = idx / run, rem = idx - cl * run;
-    const int col = rem / taps, t = rem - col * taps;
-    if (ci0 + cl < Ci && co0 + col < Co)
-      grad[((i64)(ci0 + cl) * Co + co0 + col) * taps_total + tap_base + t] = tile[cl][rem];
+    const int col = rem / TAPS, t = rem - col * TAPS;
+    if (ci0 + cl < Ci && co0 + col < Co) grad[((i64)(ci0 + cl) * Co + co0 + col) * TAPS + t] = tile[cl][rem];
   }
 }
 
@@ -583,10 +590,19 @@ static int run_wgrad(int taps, int phases, const WgradArgs &base, float *grad, i
   }
   UNET_LAUNCH_CHECK("wgrad_mfma_kernel");
   ProfScope prof(PROF_WGRAD_REDUCE, 0, partial_bytes + 4.0 * slices * Co * Ci, s);
-  const i64 boxes = (i64)((Ci + 31) / 32) * ((Co + 7) / 8);
-  if (boxes >= 512 && splits <= 16) {
-    hipLaunchKernelGGL(wgrad_reduce_tile_kernel, dim3((unsigned)((Ci + 31) / 32), (unsigned)((Co + 7) / 8)), dim3(256), 0,
-                       s, (const float *)ws, grad, splits, slices, a.CoP, a.CiP, Co, Ci, slices, 0);
+  // few slices: the box kernel, with as many workgroups as the layer allows (8 or 4 output channels per box);
+  // many slices (small layers): one workgroup per (tap, co, 32 ci) row, the slices spread over its 8 groups
+  const i64 boxes8 = (i64)((Ci + 31) / 32) * ((Co + 7) / 8), boxes4 = (i64)((Ci + 31) / 32) * ((Co + 3) / 4);
+  static const int tile_max_splits = getenv("UNET_LAB_REDUCE_TILE_SPLITS") ? atoi(getenv("UNET_LAB_REDUCE_TILE_SPLITS")) : 32;
+  const int cob = boxes8 >= 512 ? 8 : 4;
+  if (splits <= tile_max_splits && (cob == 8 ? boxes8 : boxes4) >= 256) {
+    const dim3 tgrid((unsigned)((Ci + 31) / 32), (unsigned)((Co + cob - 1) / cob));
+    if (slices == 9)
+      hipLaunchKernelGGL(wgrad_reduce_tile_kernel<9>, tgrid, dim3(32 * cob), 0, s, (const float *)ws, grad, splits, a.CoP,
+                         a.CiP, Co, Ci);
+    else
+      hipLaunchKernelGGL(wgrad_reduce_tile_kernel<4>, tgrid, dim3(32 * cob), 0, s, (const float *)ws, grad, splits, a.CoP,
+                         a.CiP, Co, Ci);
   } else {
     const i64 reduce_rows = (i64)slices * Co * ((Ci + 31) / 32);
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(reduce_rows < 65536 ? reduce_rows : 65536)), dim3(256), 0,
