@@ -394,7 +394,7 @@ struct PoolSrc {
   int ld, W;            // W: width of the full-resolution image (even)
 };
 
-template <int ACT>
+template <int ACT, bool NT>
 __device__ __forceinline__ void pool_window_grads(const PoolSrc &ps, const bf16_t *__restrict__ dy1, int ld1,
                                                   const bf16_t *__restrict__ z, int z_ld, i64 o, int cg, int CG,
                                                   const ChanFwd (&c)[8], float (&g)[4][8], float (&zv)[4][8],
@@ -408,10 +408,10 @@ __device__ __forceinline__ void pool_window_grads(const PoolSrc &ps, const bf16_
   const uint4 rp = *reinterpret_cast<const uint4 *>(ps.dy + o * ps.ld + cg * 8);
   const uint2 mk = *reinterpret_cast<const uint2 *>(ps.mask + o * (CG * 8) + cg * 8);
 #pragma unroll
-  for (int k = 0; k < 4; ++k) rz[k] = *reinterpret_cast<const uint4 *>(z + (pix + off[k]) * z_ld + cg * 8);
+  for (int k = 0; k < 4; ++k) rz[k] = ld16<NT>(z + (pix + off[k]) * z_ld + cg * 8);
   if (dy1) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) r1[k] = *reinterpret_cast<const uint4 *>(dy1 + (pix + off[k]) * ld1 + cg * 8);
+    for (int k = 0; k < 4; ++k) r1[k] = ld16<NT>(dy1 + (pix + off[k]) * ld1 + cg * 8);
   } else {
 #pragma unroll
     for (int k = 0; k < 4; ++k) r1[k] = make_uint4(0, 0, 0, 0);
@@ -452,7 +452,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_pool_kernel(const bf16_t *_
     for (i64 o = o0 + pl; o < o1; o += PL) {
       float g[4][8], zv[4][8];
       i64 pix;
-      pool_window_grads<ACT>(ps, dy1, ld1, z, z_ld, o, cg, CG, c, g, zv, pix);
+      pool_window_grads<ACT, false>(ps, dy1, ld1, z, z_ld, o, cg, CG, c, g, zv, pix);
 #pragma unroll
       for (int k = 0; k < 4; ++k)
 #pragma unroll
@@ -480,7 +480,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_pool_kernel(const bf16_t *_
 }
 
 // pass 2 over windows: dz = c0*(g - k1 - xhat*k2) and, with BIAS, per-block sums of dz
-template <int ACT, bool BIAS>
+template <int ACT, bool BIAS, bool NT>
 __global__ __launch_bounds__(256) void bn_bwd_apply_pool_kernel(const bf16_t *__restrict__ dy1, int ld1, PoolSrc ps,
                                                                 const bf16_t *__restrict__ z, int z_ld,
                                                                 const ChanFwd *__restrict__ cf,
@@ -506,7 +506,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_pool_kernel(const bf16_t *__
     for (i64 o = o0 + pl; o < o1; o += PL) {
       float g[4][8], zv[4][8];
       i64 pix;
-      pool_window_grads<ACT>(ps, dy1, ld1, z, z_ld, o, cg, CG, c, g, zv, pix);
+      pool_window_grads<ACT, NT>(ps, dy1, ld1, z, z_ld, o, cg, CG, c, g, zv, pix);
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         float out[8];
@@ -516,7 +516,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_pool_kernel(const bf16_t *__
           out[j] = b[j].c0 * (g[k][j] - b[j].k1 - xh * b[j].k2);
         }
         const uint4 packed = pack8(out);
-        *reinterpret_cast<uint4 *>(dz + (pix + (k >> 1) * (i64)ps.W + (k & 1)) * dz_ld + cg * 8) = packed;
+        st16<NT>(dz + (pix + (k >> 1) * (i64)ps.W + (k & 1)) * dz_ld + cg * 8, packed);
         if (BIAS) {
           float r[8];
           unpack8(packed, r);
@@ -602,7 +602,7 @@ __global__ __launch_bounds__(256) void maxpool2_kernel(const bf16_t *__restrict_
 // bn_act and the 2x2 max pool that follows it in one pass: a lane owns one pooling window of 8 channels, writes the
 // four activations, their maximum and the tie mask (same values as bn_act_kernel followed by maxpool2_kernel:
 // the maximum is taken over the rounded bf16 activations).
-template <int ACT>
+template <int ACT, bool NT>
 __global__ __launch_bounds__(256) void bn_act_pool_kernel(const bf16_t *__restrict__ z, int z_ld,
                                                           bf16_t *__restrict__ y, int y_ld,
                                                           const ChanFwd *__restrict__ cf,
@@ -620,10 +620,10 @@ __global__ __launch_bounds__(256) void bn_act_pool_kernel(const bf16_t *__restri
     const i64 pix = (n * H + 2 * ho) * W + 2 * wo;
     const bf16_t *zp = z + pix * z_ld + cg * 8;
     uint4 in[4];
-    in[0] = *reinterpret_cast<const uint4 *>(zp);
-    in[1] = *reinterpret_cast<const uint4 *>(zp + z_ld);
-    in[2] = *reinterpret_cast<const uint4 *>(zp + (i64)W * z_ld);
-    in[3] = *reinterpret_cast<const uint4 *>(zp + (i64)W * z_ld + z_ld);
+    in[0] = ld16<NT>(zp);
+    in[1] = ld16<NT>(zp + z_ld);
+    in[2] = ld16<NT>(zp + (i64)W * z_ld);
+    in[3] = ld16<NT>(zp + (i64)W * z_ld + z_ld);
     float ca[8], cb[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -645,7 +645,7 @@ __global__ __launch_bounds__(256) void bn_act_pool_kernel(const bf16_t *__restri
         r[j] = a;
       }
       const uint4 packed = pack8(r);
-      *reinterpret_cast<uint4 *>(yq + (i64)(k >> 1) * W * y_ld + (k & 1) * y_ld) = packed;
+      st16<NT>(yq + (i64)(k >> 1) * W * y_ld + (k & 1) * y_ld, packed);
       unpack8(packed, v[k]);
     }
     float m[8];
@@ -972,6 +972,8 @@ int unet_bn_act_backward_pooled_bf16(const uint16_t *dy, int dy_ld, const uint16
   const size_t lds1 = sizeof(float) * (size_t)pl.PL * pl.CG * 16, lds2 = sizeof(float) * (size_t)pl.PL * pl.CG * 8;
   // bytes per element: z (+ dz), the full-resolution gradient, a quarter of a pooled gradient and of a mask byte
   const double elems = (double)pixels * CoP, grads = (dy ? 2.0 : 0.0) + 0.75;
+  const RedPlan pa = plan_stream(CoP, windows, 1, 2 * stream_trips());  // the apply pass when it writes no partials
+  const bool nt = stream_nontemporal(elems * (4.0 + grads));
 #define BWD_LAUNCH(ACT_)                                                                                            \
   do {                                                                                                              \
     {                                                                                                               \
@@ -986,13 +988,19 @@ int unet_bn_act_backward_pooled_bf16(const uint16_t *dy, int dy_ld, const uint16
     {                                                                                                               \
       ProfScope prof(PROF_BN_BWD_APPLY_BF16, 0, elems * (4.0 + grads), as_stream(s));                               \
       if (grad_bias)                                                                                                \
-        hipLaunchKernelGGL((bn_bwd_apply_pool_kernel<ACT_, true>), dim3(pl.blocks), dim3(256), lds2, as_stream(s),  \
-                           d1, dy_ld, ps, zz, z_ld, cf, (const ChanBwd *)cb, reinterpret_cast<bf16_t *>(dz), dz_ld, \
-                           pl.CG, pl.PL, windows, pl.ppb, bias_part, CoP);                                          \
+        hipLaunchKernelGGL((bn_bwd_apply_pool_kernel<ACT_, true, false>), dim3(pl.blocks), dim3(256), lds2,          \
+                           as_stream(s), d1, dy_ld, ps, zz, z_ld, cf, (const ChanBwd *)cb,                          \
+                           reinterpret_cast<bf16_t *>(dz), dz_ld, pl.CG, pl.PL, windows, pl.ppb, bias_part, CoP);   \
+      else if (nt)                                                                                                  \
+        hipLaunchKernelGGL((bn_bwd_apply_pool_kernel<ACT_, false, true>), dim3(pa.blocks), dim3(256), 0,            \
+                           as_stream(s), d1, dy_ld, ps, zz, z_ld, cf, (const ChanBwd *)cb,                          \
+                           reinterpret_cast<bf16_t *>(dz), dz_ld, pa.CG, pa.PL, windows, pa.ppb, (float *)nullptr,  \
+                           CoP);                                                                                    \
       else                                                                                                          \
-        hipLaunchKernelGGL((bn_bwd_apply_pool_kernel<ACT_, false>), dim3(pl.blocks), dim3(256), 0, as_stream(s),    \
-                           d1, dy_ld, ps, zz, z_ld, cf, (const ChanBwd *)cb, reinterpret_cast<bf16_t *>(dz), dz_ld, \
-                           pl.CG, pl.PL, windows, pl.ppb, (float *)nullptr, CoP);                                   \
+        hipLaunchKernelGGL((bn_bwd_apply_pool_kernel<ACT_, false, false>), dim3(pa.blocks), dim3(256), 0,           \
+                           as_stream(s), d1, dy_ld, ps, zz, z_ld, cf, (const ChanBwd *)cb,                          \
+                           reinterpret_cast<bf16_t *>(dz), dz_ld, pa.CG, pa.PL, windows, pa.ppb, (float *)nullptr,  \
+                           CoP);                                                                                    \
     }                                                                                                               \
     UNET_LAUNCH_CHECK("bn_bwd_apply_pool_kernel");                                                                  \
   } while (0)
@@ -1072,15 +1080,19 @@ int unet_bn_act_pool_bf16(const uint16_t *z, int z_ld, uint16_t *y, int y_ld, co
   // read z, write y, write a quarter of y again (pooled) and a quarter of a byte of mask per element
   ProfScope prof(PROF_BN_ACT_BF16, 0, (double)N * H * W * CoP * 4.75, as_stream(s));
   const dim3 grid(ew_grid(total));
-  if (act == 0)
-    hipLaunchKernelGGL(bn_act_pool_kernel<0>, grid, dim3(256), 0, as_stream(s), z, z_ld, y, y_ld, cf, pooled,
-                       pooled_ld, mask, CoP / 8, H, W, total);
-  else if (act == 1)
-    hipLaunchKernelGGL(bn_act_pool_kernel<1>, grid, dim3(256), 0, as_stream(s), z, z_ld, y, y_ld, cf, pooled,
-                       pooled_ld, mask, CoP / 8, H, W, total);
-  else
-    hipLaunchKernelGGL(bn_act_pool_kernel<2>, grid, dim3(256), 0, as_stream(s), z, z_ld, y, y_ld, cf, pooled,
-                       pooled_ld, mask, CoP / 8, H, W, total);
+#define POOL_LAUNCH(ACT_, NT_)                                                                                  \
+  hipLaunchKernelGGL((bn_act_pool_kernel<ACT_, NT_>), grid, dim3(256), 0, as_stream(s), z, z_ld, y, y_ld, cf,   \
+                     pooled, pooled_ld, mask, CoP / 8, H, W, total)
+  if (stream_nontemporal((double)N * H * W * CoP * 4.75)) {
+    if (act == 0) POOL_LAUNCH(0, true);
+    else if (act == 1) POOL_LAUNCH(1, true);
+    else POOL_LAUNCH(2, true);
+  } else {
+    if (act == 0) POOL_LAUNCH(0, false);
+    else if (act == 1) POOL_LAUNCH(1, false);
+    else POOL_LAUNCH(2, false);
+  }
+#undef POOL_LAUNCH
   UNET_LAUNCH_CHECK("bn_act_pool_kernel");
   return UNET_OK;
 }

@@ -133,6 +133,39 @@ __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ w, const 
   }
 }
 
+// Four parameters per lane (16-byte accesses), a contiguous piece of the vectors per workgroup.  The moments are
+// touched once per step and are twice the size of the parameters: they stream past the caches (non-temporal),
+// as does the gradient; the parameters themselves are written normally (the weight repack reads them next).
+typedef float adam_f32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void adam_vec4_kernel(adam_f32x4 *__restrict__ w, const adam_f32x4 *__restrict__ g,
+                                                        adam_f32x4 *__restrict__ st, i64 n4, float lr, float c1,
+                                                        float c2) {
+  const float b1 = 0.9f, b2 = 0.999f, eps = 1e-8f, wd = 1e-4f;
+  constexpr int U = 2;
+  const i64 base = (i64)blockIdx.x * (256 * U);
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const i64 i = base + u * 256 + threadIdx.x;
+    if (i >= n4) break;
+    const adam_f32x4 gi = __builtin_nontemporal_load(g + i);
+    adam_f32x4 s0 = __builtin_nontemporal_load(st + 2 * i), s1 = __builtin_nontemporal_load(st + 2 * i + 1);
+    adam_f32x4 wi = w[i];
+    float m[4] = {s0.x, s0.z, s1.x, s1.z}, v[4] = {s0.y, s0.w, s1.y, s1.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      m[j] = b1 * m[j] + (1.0f - b1) * gi[j];
+      v[j] = b2 * v[j] + (1.0f - b2) * (gi[j] * gi[j]);
+      const float mh = m[j] / c1, vh = v[j] / c2;
+      wi[j] = wi[j] - lr * (wd * wi[j] + mh / (sqrtf(vh) + eps));
+    }
+    s0 = adam_f32x4{m[0], v[0], m[1], v[1]};
+    s1 = adam_f32x4{m[2], v[2], m[3], v[3]};
+    __builtin_nontemporal_store(s0, st + 2 * i);
+    __builtin_nontemporal_store(s1, st + 2 * i + 1);
+    w[i] = wi;
+  }
+}
+
 // ---- init ---------------------------------------------------------------------
 __device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
   x += 0x9E3779B97F4A7C15ull;
@@ -671,9 +704,22 @@ int unet_update_weights_adam_f32(float *weights, const float *dLdW, float *adam_
   UNET_REQUIRE(weights && dLdW && adam_parameters, "unet_update_weights_adam_f32: NULL pointer");
   const float c1 = (float)(1.0 - pow(0.9, (double)t));
   const float c2 = (float)(1.0 - pow(0.999, (double)t));
-  hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n)), dim3(256), 0, as_stream(s), weights, dLdW,
-                     reinterpret_cast<float2 *>(adam_parameters), (i64)n, lr, c1, c2);
-  UNET_LAUNCH_CHECK("adam_kernel");
+  // the body of the vectors in 16-byte pieces when they are aligned for it, the rest (at most 3 values, or
+  // everything) one value per lane; both kernels do the same arithmetic per parameter
+  const bool aligned = ((((uintptr_t)weights) | ((uintptr_t)dLdW)) & 15) == 0 && (((uintptr_t)adam_parameters) & 31) == 0;
+  const i64 n4 = aligned ? (i64)n / 4 : 0;
+  if (n4 > 0) {
+    hipLaunchKernelGGL(adam_vec4_kernel, dim3((unsigned)((n4 + 511) / 512)), dim3(256), 0, as_stream(s),
+                       reinterpret_cast<adam_f32x4 *>(weights), reinterpret_cast<const adam_f32x4 *>(dLdW),
+                       reinterpret_cast<adam_f32x4 *>(adam_parameters), n4, lr, c1, c2);
+    UNET_LAUNCH_CHECK("adam_vec4_kernel");
+  }
+  const i64 done = 4 * n4, rest = (i64)n - done;
+  if (rest > 0) {
+    hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(rest)), dim3(256), 0, as_stream(s), weights + done, dLdW + done,
+                       reinterpret_cast<float2 *>(adam_parameters) + done, rest, lr, c1, c2);
+    UNET_LAUNCH_CHECK("adam_kernel");
+  }
   return UNET_OK;
 }
 
