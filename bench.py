@@ -206,11 +206,14 @@ def main():
     # data gradient runs them on flipped weights): conv3x3_pipe_kernel for images of at least 32 x 16 pixels
     # with enough tiles to fill the device, conv_mfma_kernel<9,64> for the rest (16 x 16 layers here).
     CONV3 = "conv3x3_pipe_kernel+conv_mfma_kernel<9,64>"
+    # 3x3 weight gradient: the direct-to-LDS kernel; the register-staged one for images of 2^30 bytes and more
+    WGRAD3 = "wgrad_dma_kernel<9,3>+wgrad_mfma_kernel<9>"
     kernel_of = {"conv3x3_fwd_bf16": CONV3, "conv3x3_dgrad_bf16": CONV3,
-                 "conv3x3_wgrad_bf16": "wgrad_mfma_kernel<9>", "tconv2x2_bf16": "conv_mfma_kernel<1,64>",
+                 "conv3x3_wgrad_bf16": WGRAD3, "tconv2x2_bf16": "conv_mfma_kernel<1,64>",
                  "tconv2x2_wgrad_bf16": "wgrad_mfma_kernel<1>"}
     # substrings of the rocprofv3 kernel names that belong to a group (for the counter-derived traffic)
-    trace_names = {CONV3: ("conv3x3_pipe_kernel<", "conv_mfma_kernel<9, 64,"), "wgrad_mfma_kernel<9>": ("wgrad_mfma_kernel<9>",),
+    trace_names = {CONV3: ("conv3x3_pipe_kernel<", "conv_mfma_kernel<9, 64,"),
+                   WGRAD3: ("wgrad_dma_kernel<9", "wgrad_mfma_kernel<9>"),
                    "conv_mfma_kernel<1,64>": ("conv_mfma_kernel<1, 64,",), "wgrad_mfma_kernel<1>": ("wgrad_mfma_kernel<1>",)}
 
     def read_families():
@@ -311,7 +314,7 @@ def main():
         "final_loss": loss,
     }
     if families:
-        mfma_bound = {CONV3, "wgrad_mfma_kernel<9>", "conv_mfma_kernel<1,64>",
+        mfma_bound = {CONV3, WGRAD3, "conv_mfma_kernel<1,64>",
                       "wgrad_mfma_kernel<1>", "conv_fwd_f32", "conv_dgrad_f32", "conv_wgrad_f32", "tconv_f32"}
         # dominant kernel = the one with the largest share of device time in the probe pass; its
         # launches were timed live in the timed region

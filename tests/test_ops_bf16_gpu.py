@@ -234,8 +234,10 @@ def nchw(t, c):
     return t[..., :c].float().cpu().numpy().transpose(0, 3, 1, 2)
 
 
+# the last case is large enough (>= 32 MB per pass) for the streaming variants of the kernels: non-temporal loads
+# and stores, one contiguous piece of the tensor per workgroup
 @pytest.mark.parametrize("cfg", [(2, 64, 16, 16, 0), (1, 32, 9, 7, 0), (3, 96, 8, 8, 0), (2, 32, 8, 8, 1),
-                                 (1, 256, 4, 4, 2), (2, 24, 6, 6, 0)])
+                                 (1, 256, 4, 4, 2), (2, 24, 6, 6, 0), (3, 64, 250, 254, 0)])
 def test_bn_act_forward_backward(G, capi, oracle, cfg):
     n, c, h, w, act = cfg
     cop = (c + 7) // 8 * 8
@@ -330,8 +332,9 @@ def test_max_pool_bf16(G, capi, oracle, cfg):
     np.testing.assert_array_equal(nchw(dx, c), bf16_round(2 * dx_ref))
 
 
+# the last case is large enough (>= 32 MB per pass) for the non-temporal variants of the kernels
 @pytest.mark.parametrize("cfg", [(2, 64, 16, 16, 0, True), (1, 32, 6, 10, 0, False), (3, 96, 8, 12, 1, True),
-                                 (2, 128, 40, 24, 0, True), (1, 8, 2, 2, 2, False)])
+                                 (2, 128, 40, 24, 0, True), (1, 8, 2, 2, 2, False), (3, 64, 250, 254, 0, True)])
 def test_bn_act_with_fused_max_pool_forward_and_backward(G, capi, oracle, cfg):
     """The skip layers' fused passes (activation + pool; pool backward gathered inside the BN backward): the
     forward must give bit for bit what the separate calls give, the backward the same values up to the order of

@@ -353,6 +353,13 @@ def test_adam(G, capi, oracle, golden):
     w_ref, st_ref = oracle.adam(w0, g0, st0, 1e-3, 7)
     assert_close(G.host(wd), w_ref, rtol=1e-5, what="adam vs oracle")
     assert_close(G.host(sd), st_ref, rtol=1e-5, what="adam state vs oracle")
+    # vectors that do not start on a 16-byte boundary take the one-value-per-lane kernel for everything: the same
+    # bits as the 16-byte kernel plus its tail
+    f32 = lambda *parts: np.concatenate(parts).astype(np.float32)
+    wu, su, gu = G.dev(f32([0], w0)), G.dev(f32([0, 0], st0)), G.dev(f32([0], g0))
+    capi.unet_update_weights_adam_f32(G.p(wu) + 4, G.p(gu) + 4, G.p(su) + 8, 1e-3, n, 7, None)
+    np.testing.assert_array_equal(G.host(wu)[1:], G.host(wd))
+    np.testing.assert_array_equal(G.host(su)[2:], G.host(sd))
 
 
 def test_init_and_nan_scan(G, capi):
