@@ -98,6 +98,11 @@ CONV_CASES = [
     (3, 64, 64, 50, 30),
     (2, 96, 192, 33, 47),
     (5, 64, 128, 64, 64),    # more tiles than workgroups per channel block
+    # its 16-row tiles (images of 16 to 31 rows): resident weights and a ragged second tile row, five chunks and
+    # two channel blocks on one tile per image, ragged in both directions
+    (3, 64, 64, 20, 40),
+    (2, 160, 128, 16, 16),
+    (2, 96, 64, 31, 17),
 ]
 
 
@@ -406,7 +411,8 @@ def test_bn_act_with_fused_max_pool_forward_and_backward(G, capi, oracle, cfg):
 
 @pytest.mark.parametrize("cfg", [("conv", 2, 64, 64, 24, 40), ("conv", 1, 32, 96, 16, 16), ("tconv", 2, 64, 32, 8, 12),
                                  ("conv", 1, 64, 64, 72, 80),    # the pipelined kernel, weights resident
-                                 ("conv", 3, 128, 192, 40, 48)])  # the pipelined kernel, six K chunks, two channel blocks
+                                 ("conv", 3, 128, 192, 40, 48),   # the pipelined kernel, six K chunks, two channel blocks
+                                 ("conv", 2, 128, 128, 16, 32)])  # its 16-row tiles
 def test_dgrad_with_fused_bn_backward_reduction(G, capi, cfg):
     """The data-gradient kernels that also reduce the parent's batch-norm backward over the pixels:
     dx is bit-identical to the plain data gradient, and dz / dgamma / dbeta / dbias agree with the
@@ -621,7 +627,8 @@ def test_first_layer_with_8_stored_channels(G, capi, oracle):
 
 
 @pytest.mark.parametrize("kind,shape", [("conv", (2, 64, 96, 20, 24)), ("tconv", (2, 64, 96, 20, 24)),
-                                        ("conv", (2, 64, 128, 40, 24))])   # the last: the pipelined kernel
+                                        ("conv", (2, 64, 128, 40, 24)),    # the pipelined kernel
+                                        ("conv", (2, 64, 128, 24, 24))])   # its 16-row tiles
 def test_inference_bn_relu_folded_into_the_epilogue(G, capi, oracle, kind, shape):
     """Inference: conv / transposed conv with BN (running statistics) + ReLU folded in, against the oracle's
     convolution -> bn_inference -> relu, and against the unfused pair of entry points."""

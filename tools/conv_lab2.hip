@@ -57,7 +57,8 @@ int main(int argc, char **argv) {
   const int N = 16;
   const int wgs = argc > 1 ? atoi(argv[1]) : 256;
   std::vector<Shape> shapes = {{256, 64, 64}, {256, 128, 64}, {256, 64, 128}, {128, 128, 128}, {128, 64, 128},
-                               {64, 256, 256}, {32, 512, 512}, {32, 1024, 512}, {128, 256, 128}, {72, 64, 64}};
+                               {64, 256, 256}, {32, 512, 512}, {32, 1024, 512}, {128, 256, 128}, {72, 64, 64},
+                               {16, 512, 1024}, {16, 1024, 1024}, {16, 1024, 512}};
   size_t max_in = 0, max_out = 0, max_w = 0;
   for (auto &s : shapes) {
     max_in = std::max(max_in, (size_t)N * s.H * s.H * s.Ci);

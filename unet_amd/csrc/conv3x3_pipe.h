@@ -26,17 +26,24 @@
 
 namespace pipe {
 
-constexpr int TH = 32, TW = 16;                    // pixel tile
-constexpr int HR = TH + 2, HC = TW + 2;            // halo rows / columns
-constexpr int HALO_PIECES = HR * HC * 4;           // 16-byte pieces of one halo stage (64 B per pixel)
-constexpr int HALO_INSTR = (HALO_PIECES + 63) / 64;  // wave instructions (1 KiB each) that fill it
-constexpr int HALO_BYTES = HALO_INSTR * 1024;      // 39936: the last instruction's tail is padding
+constexpr int TW = 16;                             // pixel tile: TH_ rows (32, or 16 for images of fewer than 32 rows) x 16
+template <int TH_>
+struct Geo {
+  static constexpr int TH = TH_, QW = TH_ / 4;            // tile rows; rows per wave (4 row groups)
+  static constexpr int HR = TH_ + 2, HC = TW + 2;         // halo rows / columns
+  static constexpr int HALO_PIECES = HR * HC * 4;         // 16-byte pieces of one halo stage (64 B per pixel)
+  static constexpr int HALO_INSTR = (HALO_PIECES + 63) / 64;  // wave instructions (1 KiB each) that fill it
+  static constexpr int HALO_BYTES = HALO_INSTR * 1024;    // 39936 (TH 32): the last instruction's tail is padding
+  static constexpr int KH = (HALO_INSTR + 7) / 8;         // halo instructions per wave, at most
+  static constexpr int STAGE_BYTES = HALO_BYTES + 9 * 64 * 64;
+  static constexpr int STAGES_BYTES = 2 * STAGE_BYTES;    // (resident weights: 2 * HALO_BYTES + 2 * W_BYTES)
+  static constexpr int LDS_BYTES = STAGES_BYTES + 64 * 16;  // + the batch-norm records of the 64 channels (EPI_BRED)
+};
+constexpr int TH = 32;                             // the tile height of the main variant
 constexpr int W_INSTR = 9 * 64 * 4 / 64;           // 36
 constexpr int W_BYTES = W_INSTR * 1024;            // 36864: 9 taps x 64 channels x 64 B
-constexpr int STAGE_BYTES = HALO_BYTES + W_BYTES;  // 76800
 constexpr int MAX_WS_CHUNKS = 2;                   // weights resident in LDS up to C_in = 64
-constexpr int STAGES_BYTES = 2 * STAGE_BYTES;       // 153600 (resident weights: 2 * HALO_BYTES + 2 * W_BYTES)
-constexpr int LDS_BYTES = STAGES_BYTES + 64 * 16;  // + the batch-norm records of the 64 channels (EPI_BRED)
+constexpr int LDS_BYTES = Geo<32>::LDS_BYTES;      // 154624
 
 struct Args {
   const bf16_t *in;
@@ -86,8 +93,8 @@ enum Epi {
   EPI_BRED = 3,   // data gradient + the BN-backward pixel sums of the layer that produced the input
   EPI_AFF = 4,    // inference: relu(a * (conv + bias) + b) with per-channel {a, b}
 };
-constexpr int epi_vmem_ops(int epi) {  // vector-memory instructions a wave issues per tile epilogue
-  return (epi == EPI_ACC || epi == EPI_BRED) ? 16 : 8;
+constexpr int epi_vmem_ops(int epi, int qw) {  // vector-memory instructions a wave issues per tile epilogue
+  return (epi == EPI_ACC || epi == EPI_BRED) ? 2 * qw : qw;
 }
 
 // Lanes 16 apart exchange halves (v_permlane16_swap: odd 16-lane rows of the first operand <-> even rows of
@@ -119,9 +126,12 @@ __device__ __forceinline__ void wait_vmem_then_barrier() {
   asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
 }
 
-template <bool WS, int EPI>
+template <bool WS, int EPI, int TH_ = 32>
 __global__ __launch_bounds__(512, 2) void conv3x3_pipe_kernel(const Args a) {
   constexpr bool BRED = EPI == EPI_BRED, AFF = EPI == EPI_AFF, STATS = EPI == EPI_STATS || EPI == EPI_BRED;
+  typedef Geo<TH_> G;
+  constexpr int TH = G::TH, QW = G::QW, HR = G::HR, HC = G::HC, HALO_INSTR = G::HALO_INSTR, HALO_BYTES = G::HALO_BYTES,
+                KH = G::KH, STAGE_BYTES = G::STAGE_BYTES, STAGES_BYTES = G::STAGES_BYTES;
   extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
   // WS: [halo 0][halo 1][weights chunk 0][weights chunk 1];  else: [halo 0][weights 0][halo 1][weights 1]
   const int tid = threadIdx.x, lane = tid & 63;
@@ -144,16 +154,19 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pipe_kernel(const Args a) {
   // wave instruction i fills LDS bytes [1024 i, 1024 i + 1024) of its region; lane l's 16 bytes are LDS row
   // r = 16 i + l / 4, slot l % 4, which the swizzled image assigns to piece slot ^ ((r >> 1) & 3) of row r
   constexpr unsigned OOB = 0x80000000u;
-  int h_rel[5], h_pyx[5];   // halo: byte offset relative to the tile origin pixel; (py << 8) | px, or -1
-  unsigned w_rel[5];        // weights: byte offset within one chunk's slab
+  int h_rel[KH], h_pyx[KH];  // halo: byte offset relative to the tile origin pixel; (py << 8) | px, or -1
+  unsigned w_rel[5];         // weights: byte offset within one chunk's slab
 #pragma unroll
-  for (int k = 0; k < 5; ++k) {
+  for (int k = 0; k < KH; ++k) {
     const int i = wave + 8 * k;
     const int r = 16 * i + (lane >> 2), piece = (lane & 3) ^ ((r >> 1) & 3);
     const int py = r / HC, px = r - py * HC;
     const bool ok = i < HALO_INSTR && r < HR * HC && (a.in_c == 0 || piece * 8 < a.in_c);
     h_rel[k] = (((py - 1) * a.W + (px - 1)) * a.in_ld + piece * 8) * 2;
     h_pyx[k] = ok ? ((py << 8) | px) : -1;
+  }
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
     const int j = (7 - wave) + 8 * k;  // the waves with one halo instruction fewer take one weight instruction more
     const int rw = 16 * j + (lane >> 2), pw = (lane & 3) ^ ((rw >> 1) & 3);
     const int tap = rw >> 6, co = rw & 63;
@@ -185,7 +198,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pipe_kernel(const Args a) {
                                                        img_bytes, 0x00020000);
     const int org = ((y0 * a.W + x0) * a.in_ld + kc * 32) * 2;
 #pragma unroll
-    for (int k = 0; k < 5; ++k) {
+    for (int k = 0; k < KH; ++k) {
       const int i = wave + 8 * k;
       if (i < HALO_INSTR) {
         const int py = h_pyx[k] >> 8, px = h_pyx[k] & 255;
@@ -208,7 +221,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pipe_kernel(const Args a) {
 #pragma unroll
     for (int rc = 0; rc < 4; ++rc) {
       const int pl = rc * HC + l15 + kw;
-      b4_off[kw][rc] = (l15 + kw) * 64 + ((kp ^ ((pl >> 1) & 3)) * 16) + ph * 8 * HC * 64;
+      b4_off[kw][rc] = (l15 + kw) * 64 + ((kp ^ ((pl >> 1) & 3)) * 16) + ph * QW * HC * 64;
     }
 
   // ---- per-lane epilogue constants: the lane's 2 x 4 channels ----
@@ -261,27 +274,27 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pipe_kernel(const Args a) {
     const int x = x0 + l15;
     const i64 img = (i64)n * a.H * a.W;
     const auto ors = __builtin_amdgcn_make_buffer_rsrc(a.out + img * a.out_ld, 0, out_img_bytes, 0x00020000);
-    unsigned ooff[8];  // byte offset of the lane's 16 bytes in the output image, or OOB
-    bool okq[8];
+    unsigned ooff[QW];  // byte offset of the lane's 16 bytes in the output image, or OOB
+    bool okq[QW];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int y = y0 + ph * 8 + q;
+    for (int q = 0; q < QW; ++q) {
+      const int y = y0 + ph * QW + q;
       okq[q] = y < a.H && x < a.W;
       ooff[q] = okq[q] ? (unsigned)(((y * a.W + x) * a.out_ld + co0 + ch16) * 2) : OOB;
     }
-    i32x4 zq[BRED ? 8 : 1], oq[EPI == EPI_ACC ? 8 : 1];
-    f32x4 acc[2][8];
+    i32x4 zq[BRED ? QW : 1], oq[EPI == EPI_ACC ? QW : 1];
+    f32x4 acc[2][QW];
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
-      for (int q = 0; q < 8; ++q) acc[m][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int q = 0; q < QW; ++q) acc[m][q] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int kc = 0; kc < nk; ++kc, ++s) {
       // This wave's pieces of stage s have landed; after the barrier everybody's have, and everybody has
       // finished reading the other buffer (stage s-1), which the next loads overwrite.  The first stage of
       // a tile follows the previous tile's epilogue, whose stores were issued after these loads and need not
       // be waited for.
       if (kc == 0 && it > 0)
-        wait_vmem_then_barrier<epi_vmem_ops(EPI)>();
+        wait_vmem_then_barrier<epi_vmem_ops(EPI, QW)>();
       else
         wait_vmem_then_barrier<0>();
       if (s + 1 < S) {
@@ -300,22 +313,22 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pipe_kernel(const Args a) {
           const auto zrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(a.bz) + img * a.bz_ld, 0,
                                                              red_here ? z_img_bytes : 0u, 0x00020000);
 #pragma unroll
-          for (int q = 0; q < 8; ++q) {
-            const int y = y0 + ph * 8 + q;
+          for (int q = 0; q < QW; ++q) {
+            const int y = y0 + ph * QW + q;
             const unsigned zo = okq[q] ? (unsigned)(((y * a.W + x) * a.bz_ld + rc0 + ch16) * 2) : OOB;
             zq[BRED ? q : 0] = __builtin_amdgcn_raw_buffer_load_b128(zrs, zo, 0, 0);
           }
         } else {
 #pragma unroll
-          for (int q = 0; q < 8; ++q) oq[EPI == EPI_ACC ? q : 0] = __builtin_amdgcn_raw_buffer_load_b128(ors, ooff[q], 0, 0);
+          for (int q = 0; q < QW; ++q) oq[EPI == EPI_ACC ? q : 0] = __builtin_amdgcn_raw_buffer_load_b128(ors, ooff[q], 0, 0);
         }
       }
       const unsigned char *ldsX = halo_buf(s), *ldsW = weight_buf(s, kc);
 #pragma unroll
       for (int kw = 0; kw < 3; ++kw) {
-        bf16x8 brow[10];
+        bf16x8 brow[QW + 2];
 #pragma unroll
-        for (int r = 0; r < 10; ++r)
+        for (int r = 0; r < QW + 2; ++r)
           brow[r] = *reinterpret_cast<const bf16x8 *>(ldsX + r * HC * 64 + b4_off[kw][r & 3]);
 #pragma unroll
         for (int kh = 0; kh < 3; ++kh) {
@@ -326,7 +339,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pipe_kernel(const Args a) {
 #pragma unroll
           for (int m = 0; m < 2; ++m)
 #pragma unroll
-            for (int q = 0; q < 8; ++q)
+            for (int q = 0; q < QW; ++q)
 #if PIPE_LAB_ABLATE == 2
               if (a.N < 0)
 #endif
@@ -348,7 +361,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pipe_kernel(const Args a) {
         for (int j = 0; j < 4; ++j) bcf[BRED ? m * 4 + j : 0] = lds_cf[(cw * 2 + m) * 16 + 4 * kp + j];
     }
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
+    for (int q = 0; q < QW; ++q) {
       typedef u32x2_t u32x2;
       u32x2 hw[2];   // the rounded result, matrix-core layout: hw[m] = 4 channels of block m
       f32x4 rv[2];   // the same as floats (what the statistics see)
@@ -428,8 +441,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pipe_kernel(const Args a) {
 }
 
 // Launch plan: persistent workgroups, a multiple of the channel-block count, at most one per tile and channel block.
+// th = tile_rows(H): 32-row tiles, 16-row tiles for images of fewer than 32 rows.
+inline int tile_rows(int H) {
+  static const int forced = getenv("UNET_LAB_PIPE_TILE_ROWS") ? atoi(getenv("UNET_LAB_PIPE_TILE_ROWS")) : 0;  // laboratory switch
+  if (forced == 16 || (forced == 32 && H >= 32)) return forced;
+  return H >= 32 ? 32 : 16;
+}
 inline int plan_grid(int N, int H, int W, int CoP, int max_wgs = 256) {
-  const int co_blocks = CoP / 64, units = N * ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
+  const int th = tile_rows(H), co_blocks = CoP / 64, units = N * ((H + th - 1) / th) * ((W + TW - 1) / TW);
   int per_block = max_wgs / co_blocks;
   if (per_block < 1) per_block = 1;
   if (per_block > units) per_block = units;
@@ -438,17 +457,22 @@ inline int plan_grid(int N, int H, int W, int CoP, int max_wgs = 256) {
 // Rows of partial sums the kernel writes (in all, not per image): four per workgroup of a channel block.
 inline int stat_rows(int N, int H, int W, int CoP, int max_wgs = 256) { return 4 * (plan_grid(N, H, W, CoP, max_wgs) / (CoP / 64)); }
 
-// Whether the pipelined kernel serves this call.  It needs images of 32 rows and more, 64-channel output
+// Whether the pipelined kernel serves this call.  It needs images of 16 rows and more, 64-channel output
 // blocks, and enough (tile, channel block) units to give every CU a workgroup: below that (single images at
 // inference, the deepest levels) the general kernel's smaller workgroups spread the work better.  The two
 // kernels return bit-identical outputs, so the choice may depend on the batch size.
-inline int &min_units() {
-  static int v = 256;
+inline int &min_units() {  // UNET_LAB_PIPE_MIN_UNITS: laboratory switch
+  static int v = getenv("UNET_LAB_PIPE_MIN_UNITS") ? atoi(getenv("UNET_LAB_PIPE_MIN_UNITS")) : 128;
+  return v;
+}
+inline int &min_rows() {  // laboratory switch: 32 keeps the 16-row variant off
+  static int v = getenv("UNET_LAB_PIPE_MIN_ROWS") ? atoi(getenv("UNET_LAB_PIPE_MIN_ROWS")) : 16;
   return v;
 }
 inline bool eligible(int N, int H, int W, int CiP, int CoP) {
-  if (!(H >= 32 && W >= 16 && CoP % 64 == 0 && CiP % 32 == 0)) return false;
-  return (i64)N * ((H + TH - 1) / TH) * ((W + TW - 1) / TW) * (CoP / 64) >= min_units();
+  if (!(H >= min_rows() && H >= 16 && W >= 16 && CoP % 64 == 0 && CiP % 32 == 0)) return false;
+  const int th = tile_rows(H);
+  return (i64)N * ((H + th - 1) / th) * ((W + TW - 1) / TW) * (CoP / 64) >= min_units();
 }
 
 }  // namespace pipe

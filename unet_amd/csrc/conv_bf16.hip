@@ -460,10 +460,12 @@ int launch_pipe_from(const ConvArgs &c, hipStream_t s);
 int launch_conv_any(int taps, const ConvArgs &a, hipStream_t s) {
   if (taps == 9 && pipe::eligible(a.N, a.Ho, a.Wo, a.Ci, a.CoP) && !(a.accumulate && a.stats)) return launch_pipe_from(a, s);
   const bool wide = a.CoP % 64 == 0, deep = a.Ci % 64 == 0;
-  // the 16x16x32 path for all but the smallest images (at batch 16: wherever a launch has more than one workgroup
-  // per CU).  The choice must not depend on the batch size: the two loops add in different orders, and inference
-  // on one image has to give bit for bit what the same image gives inside a batch.
-  const bool mma16 = taps == 9 && wide && (i64)a.tilesX * ((a.Ho + 15) / 16) * (a.CoP / 64) > 16;
+  // the 16x16x32 path for every image the pipelined kernel could take at some batch size (16 x 16 pixels and
+  // more), and for smaller ones with many tiles.  The choice must not depend on the batch size: the two loops
+  // add in different orders, and inference on one image has to give bit for bit what the same image gives
+  // inside a batch -- whichever of the two kernels the batch size selects.
+  const bool mma16 = taps == 9 && wide &&
+                     ((a.Ho >= 16 && a.Wo >= 16) || (i64)a.tilesX * ((a.Ho + 15) / 16) * (a.CoP / 64) > 16);
   if (a.affine) {  // inference forward
     if (mma16) return launch_conv<9, 64, false, 32, 1, true>(a, s);
     if (taps == 9) return wide ? launch_conv<9, 64, false, 32, 0, true>(a, s) : launch_conv<9, 32, false, 32, 0, true>(a, s);
@@ -484,30 +486,34 @@ int launch_conv_any(int taps, const ConvArgs &a, hipStream_t s) {
 // The pipelined persistent kernel (conv3x3_pipe.h) for the shapes it serves; returns false when the shape
 // stays with conv_mfma_kernel.  Both add in the same order: their outputs are bit-identical, so one image gives
 // the same result alone (general kernel) and inside a batch (pipelined kernel).
-template <bool WS, int EPI>
+template <bool WS, int EPI, int TH>
 int launch_pipe(const pipe::Args &a, int grid, hipStream_t s) {
   static bool attr_set[64] = {};
   int dev = 0;
   UNET_HIP_TRY(hipGetDevice(&dev));
   if (!attr_set[dev & 63]) {
-    UNET_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&pipe::conv3x3_pipe_kernel<WS, EPI>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, pipe::LDS_BYTES));
+    UNET_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&pipe::conv3x3_pipe_kernel<WS, EPI, TH>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, pipe::Geo<TH>::LDS_BYTES));
     attr_set[dev & 63] = true;
   }
-  hipLaunchKernelGGL((pipe::conv3x3_pipe_kernel<WS, EPI>), dim3((unsigned)grid), dim3(512), pipe::LDS_BYTES, s, a);
+  hipLaunchKernelGGL((pipe::conv3x3_pipe_kernel<WS, EPI, TH>), dim3((unsigned)grid), dim3(512), pipe::Geo<TH>::LDS_BYTES, s,
+                     a);
   UNET_LAUNCH_CHECK("conv3x3_pipe_kernel");
   return UNET_OK;
 }
 template <int EPI>
 int launch_pipe_ws(const pipe::Args &a, int grid, hipStream_t s) {
-  return a.nk <= pipe::MAX_WS_CHUNKS ? launch_pipe<true, EPI>(a, grid, s) : launch_pipe<false, EPI>(a, grid, s);
+  if (pipe::tile_rows(a.H) == 16)
+    return a.nk <= pipe::MAX_WS_CHUNKS ? launch_pipe<true, EPI, 16>(a, grid, s) : launch_pipe<false, EPI, 16>(a, grid, s);
+  return a.nk <= pipe::MAX_WS_CHUNKS ? launch_pipe<true, EPI, 32>(a, grid, s) : launch_pipe<false, EPI, 32>(a, grid, s);
 }
 int launch_pipe_from(const ConvArgs &c, hipStream_t s) {
   pipe::Args a{};
   a.in = c.in; a.wt = c.wt; a.bias = c.bias; a.out = c.out; a.stats = c.stats;
   a.N = c.N; a.H = c.Ho; a.W = c.Wo; a.nk = c.Ci / 32; a.CoP = c.CoP;
   a.in_ld = c.in_ld; a.out_ld = c.out_ld; a.in_c = c.in_c;
-  a.tilesX = (c.Wo + pipe::TW - 1) / pipe::TW; a.tilesY = (c.Ho + pipe::TH - 1) / pipe::TH;
+  const int th = pipe::tile_rows(c.Ho);
+  a.tilesX = (c.Wo + pipe::TW - 1) / pipe::TW; a.tilesY = (c.Ho + th - 1) / th;
   a.units = c.N * a.tilesX * a.tilesY; a.co_blocks = c.CoP / 64; a.co_valid = c.co_valid;
   a.accumulate = c.accumulate;
   a.bz = c.bz; a.bz_ld = c.bz_ld; a.bcf = c.bcf; a.bred_c0 = c.bred_c0; a.affine = c.affine;
