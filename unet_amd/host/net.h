@@ -1122,9 +1122,10 @@ class Net {
         // BN-backward sums arrive from the consumer's data-gradient kernel (a 3x3 convolution over this
         // layer's output grid, a transposed convolution whose input grid it is, or the head): room for the
         // larger of the row counts those kernels use
-        const size_t strips = b * (size_t)((n.out_h + 31) / 32) * ((n.out_w + 15) / 16);
-        const size_t bwd_rows = std::max<size_t>(b * (size_t)unet_conv3x3_stat_tiles(n.out_h, n.out_w),
-                                                 std::min<size_t>(4 * strips, 1024));
+        // (the pipelined 3x3 kernel writes four rows per workgroup, with at most 256 workgroups and at most one
+        // per 16-row tile -- its smallest tile -- whatever tile height it picks for the shape)
+        const size_t tiles16 = b * (size_t)unet_conv3x3_stat_tiles(n.out_h, n.out_w);
+        const size_t bwd_rows = std::max<size_t>(tiles16, std::min<size_t>(4 * tiles16, 1024));
         n.bwd_partials.ensure(sizeof(float) * bwd_rows * n.cop * 2);
         max_dz = std::max(max_dz, 2 * pix * n.cop);
         const size_t taps = n.type == CONV_LAYER ? 9 : 4;
