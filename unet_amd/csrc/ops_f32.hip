@@ -144,9 +144,18 @@ __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ w, const 
 // as does the gradient; the parameters themselves are written normally (the weight repack reads them next).
 typedef float adam_f32x4 __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void adam_vec4_kernel(adam_f32x4 *__restrict__ w, const adam_f32x4 *__restrict__ g,
-                                                        adam_f32x4 *__restrict__ st, i64 n4, float lr, float c1,
-                                                        float c2) {
+                                                        adam_f32x4 *__restrict__ st, i64 n4, int tail, float lr,
+                                                        float c1, float c2) {
   constexpr int U = 2;
+  if (blockIdx.x == 0 && (int)threadIdx.x < tail) {  // the up to three values behind the last 16-byte piece
+    float *ws = reinterpret_cast<float *>(w + n4) + threadIdx.x;
+    float2 *ss = reinterpret_cast<float2 *>(st + 2 * n4) + threadIdx.x;
+    float2 mv = *ss;
+    float wi = *ws;
+    adam_update(wi, reinterpret_cast<const float *>(g + n4)[threadIdx.x], mv.x, mv.y, lr, c1, c2);
+    *ss = mv;
+    *ws = wi;
+  }
   const i64 base = (i64)blockIdx.x * (256 * U);
 #pragma unroll
   for (int u = 0; u < U; ++u) {
@@ -706,20 +715,18 @@ int unet_update_weights_adam_f32(float *weights, const float *dLdW, float *adam_
   UNET_REQUIRE(weights && dLdW && adam_parameters, "unet_update_weights_adam_f32: NULL pointer");
   const float c1 = (float)(1.0 - pow(0.9, (double)t));
   const float c2 = (float)(1.0 - pow(0.999, (double)t));
-  // the body of the vectors in 16-byte pieces when they are aligned for it, the rest (at most 3 values, or
-  // everything) one value per lane; both kernels do the same arithmetic per parameter
+  // 16-byte pieces when the vectors are aligned for it (the up to three values behind the last piece go to
+  // three lanes of the first workgroup), else one value per lane; both kernels do the same arithmetic per parameter
   const bool aligned = ((((uintptr_t)weights) | ((uintptr_t)dLdW)) & 15) == 0 && (((uintptr_t)adam_parameters) & 31) == 0;
   const i64 n4 = aligned ? (i64)n / 4 : 0;
   if (n4 > 0) {
     hipLaunchKernelGGL(adam_vec4_kernel, dim3((unsigned)((n4 + 511) / 512)), dim3(256), 0, as_stream(s),
                        reinterpret_cast<adam_f32x4 *>(weights), reinterpret_cast<const adam_f32x4 *>(dLdW),
-                       reinterpret_cast<adam_f32x4 *>(adam_parameters), n4, lr, c1, c2);
+                       reinterpret_cast<adam_f32x4 *>(adam_parameters), n4, (int)(n - 4 * n4), lr, c1, c2);
     UNET_LAUNCH_CHECK("adam_vec4_kernel");
-  }
-  const i64 done = 4 * n4, rest = (i64)n - done;
-  if (rest > 0) {
-    hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(rest)), dim3(256), 0, as_stream(s), weights + done, dLdW + done,
-                       reinterpret_cast<float2 *>(adam_parameters) + done, rest, lr, c1, c2);
+  } else {
+    hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n)), dim3(256), 0, as_stream(s), weights, dLdW,
+                       reinterpret_cast<float2 *>(adam_parameters), (i64)n, lr, c1, c2);
     UNET_LAUNCH_CHECK("adam_kernel");
   }
   return UNET_OK;
