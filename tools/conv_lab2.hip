@@ -70,6 +70,7 @@ int main(int argc, char **argv) {
   CK(hipMalloc(&d_w, max_w * 2));
   CK(hipMalloc(&d_out, max_out * 2));
   CK(hipMalloc(&d_ref, max_out * 2));
+  if (getenv("LAB_SWAP_OUT")) std::swap(d_out, d_ref);  // does the placement of the output buffer matter?
   {
     std::vector<bf16_t> h(std::max(max_in, max_w));
     uint32_t s = 12345;
@@ -156,10 +157,17 @@ int main(int argc, char **argv) {
       for (size_t r = 0; r < (size_t)rows; ++r) y += sn[r * 2 * s.Co + c];
       worst = std::max(worst, fabs(x - y) / (fabs(x) + 1e-3));
     }
-    const float t_lib = time_launch([&] {
+    auto launch_lib = [&] {
       unet_conv3x3_bf16(d_in, s.Ci, d_w, d_bias, s.Co, d_ref, s.Co, d_stats_ref, N, s.H, s.H, s.Ci, s.Co, 0, nullptr);
-    }, 20);
-    const float t_new = time_launch(launch, 20);
+    };
+    float t_lib, t_new;
+    if (getenv("LAB_PIPE_FIRST")) {  // does the order of the two measurements matter?
+      t_new = time_launch(launch, 20);
+      t_lib = time_launch(launch_lib, 20);
+    } else {
+      t_lib = time_launch(launch_lib, 20);
+      t_new = time_launch(launch, 20);
+    }
     // the data-gradient variant with the fused batch-norm reduction (timing only; operands: z = the reference output)
     pipe::Args b = a;
     b.bias = nullptr; b.bz = d_ref; b.bz_ld = s.Co; b.bcf = reinterpret_cast<const float4 *>(d_bcf); b.bred_c0 = 0;
