@@ -10,9 +10,9 @@ d=json.loads(sys.stdin.readline()); f=d["kernel_families"]
 print(d["ms_per_step"], "ms/step;", {k: f[k]["ms_per_step"] for k in ("bn_act_bf16","bn_bwd_apply_bf16","bn_bwd_reduce_bf16","conv3x3_fwd_bf16","conv3x3_dgrad_bf16","conv3x3_wgrad_bf16")})'
 }
 for rep in 1 2; do
-  run UNET_BN_NT=0 UNET_BN_TRIPS=2
-  run UNET_BN_NT=1 UNET_BN_TRIPS=2
-  run UNET_BN_NT=1 UNET_BN_TRIPS=1
-  run UNET_BN_NT=1 UNET_BN_TRIPS=4
-  run UNET_BN_TRIPS=2
+  run UNET_LAB_BN_NT=0 UNET_LAB_BN_TRIPS=2
+  run UNET_LAB_BN_NT=1 UNET_LAB_BN_TRIPS=2
+  run UNET_LAB_BN_NT=1 UNET_LAB_BN_TRIPS=1
+  run UNET_LAB_BN_NT=1 UNET_LAB_BN_TRIPS=4
+  run UNET_LAB_BN_TRIPS=2
 done

@@ -788,19 +788,19 @@ RedPlan plan_stream(int CoP, i64 pixels, int rows_per_trip, int trips) {
   return r;
 }
 
-// Non-temporal loads and stores for passes over tensors that no cache holds anyway.  UNET_BN_NT=0 / 1 forces the
+// Non-temporal loads and stores for passes over tensors that no cache holds anyway.  UNET_LAB_BN_NT=0 / 1 forces the
 // choice (laboratory switch); by default a pass streams when it moves at least 32 MB.
 bool stream_nontemporal(double bytes) {
   static const int forced = [] {
-    const char *e = getenv("UNET_BN_NT");
+    const char *e = getenv("UNET_LAB_BN_NT");
     return e && *e ? atoi(e) : -1;
   }();
   if (forced >= 0) return forced != 0;
   return bytes >= 32e6;
 }
-int stream_trips() {
+int stream_trips() {  // main-loop trips per workgroup of the streaming passes (UNET_LAB_BN_TRIPS: laboratory switch)
   static const int t = [] {
-    const char *e = getenv("UNET_BN_TRIPS");
+    const char *e = getenv("UNET_LAB_BN_TRIPS");
     const int v = e && *e ? atoi(e) : 2;
     return v < 1 ? 1 : v;
   }();
