@@ -60,6 +60,7 @@ struct Args {
   int xcd_order;        // 1: renumber the workgroups per XCD (needs gridDim.x % (8 * co_blocks) == 0)
   int co_valid;
   int accumulate;
+  int nt_store;         // 1: the output is stored non-temporal (large tensors that no cache holds until they are read)
   // BRED: the output is the gradient of a BN + ReLU layer's output; bz = that layer's pre-BN tensor,
   // bcf its per-channel records {a, b, mean, 1/sqrt(var+eps)}; stats receives (sum g*xhat, sum g),
   // g = out * relu'(a*z + b).  Channels below bred_c0 take no part; bz, bcf and stats are indexed by
@@ -387,7 +388,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pipe_kernel(const Args a) {
 #if PIPE_LAB_ABLATE == 1
       if (a.N < 0)
 #endif
-      __builtin_amdgcn_raw_buffer_store_b128(swap16(hw), ors, ooff[q], 0, 0);
+      if (a.nt_store)
+        __builtin_amdgcn_raw_buffer_store_b128(swap16(hw), ors, ooff[q], 0, 2);  // cache policy bit 1: nt
+      else
+        __builtin_amdgcn_raw_buffer_store_b128(swap16(hw), ors, ooff[q], 0, 0);
       if (STATS) {
 #pragma unroll
         for (int m = 0; m < 2; ++m) {

@@ -516,6 +516,16 @@ int launch_pipe_from(const ConvArgs &c, hipStream_t s) {
   a.tilesX = (c.Wo + pipe::TW - 1) / pipe::TW; a.tilesY = (c.Ho + th - 1) / th;
   a.units = c.N * a.tilesX * a.tilesY; a.co_blocks = c.CoP / 64; a.co_valid = c.co_valid;
   a.accumulate = c.accumulate;
+  {
+    // Data gradients of 60 MB and more are stored non-temporal: -3 % on that family (same-box A/B), and the
+    // batch-norm backward pass that reads them next runs as before.  Forward outputs stay cached: the
+    // normalisation pass that reads them right after the convolution was 3-6 % slower behind non-temporal stores.
+    // UNET_LAB_CONV_NT_BYTES: laboratory switch (threshold in bytes for every launch; 0 = never).
+    static const double lab_bytes = getenv("UNET_LAB_CONV_NT_BYTES") ? atof(getenv("UNET_LAB_CONV_NT_BYTES")) : -1;
+    const double out_bytes = 2.0 * c.N * c.Ho * c.Wo * c.CoP;
+    const bool data_gradient = c.bz || (!c.stats && !c.affine);
+    a.nt_store = lab_bytes >= 0 ? (lab_bytes > 0 && out_bytes >= lab_bytes) : (data_gradient && out_bytes >= 60e6);
+  }
   a.bz = c.bz; a.bz_ld = c.bz_ld; a.bcf = c.bcf; a.bred_c0 = c.bred_c0; a.affine = c.affine;
   const int grid = pipe::plan_grid(c.N, c.Ho, c.Wo, c.CoP);
   static const bool xcd_off = getenv("UNET_LAB_NO_XCD_ORDER") != nullptr;  // laboratory switch (same results either way)

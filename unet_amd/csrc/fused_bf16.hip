@@ -796,7 +796,8 @@ bool stream_nontemporal(double bytes) {
     return e && *e ? atoi(e) : -1;
   }();
   if (forced >= 0) return forced != 0;
-  return bytes >= 32e6;
+  static const double min_bytes = getenv("UNET_LAB_BN_NT_BYTES") ? atof(getenv("UNET_LAB_BN_NT_BYTES")) : 32e6;
+  return bytes >= min_bytes;
 }
 int stream_trips() {  // main-loop trips per workgroup of the streaming passes (UNET_LAB_BN_TRIPS: laboratory switch)
   static const int t = [] {
