@@ -34,9 +34,12 @@ __device__ __forceinline__ uint4 pack8(const float (&v)[8]) {
   return make_uint4(w[0], w[1], w[2], w[3]);
 }
 
-// 16-byte loads and stores of the streaming passes.  NT: non-temporal (the data is touched once per pass and
-// the tensors are far larger than the caches, so nothing is gained by keeping them; measured on 134 MB bf16
-// tensors, read + write: 5.0 -> 6.1 TB/s together with contiguous 8-32 KiB pieces per workgroup).
+// 16-byte loads and stores of the streaming passes.  NT: non-temporal.  Measured on 134 MB bf16 tensors, read +
+// write, a pass alone: 5.0 -> 6.1 TB/s with non-temporal loads and stores and contiguous 8-32 KiB pieces per
+// workgroup.  Inside the training step the passes take their INPUTS non-temporal (read once, then dead until the
+// backward pass) and store their OUTPUTS normally: the convolution that reads an output right after the pass
+// finds part of it in the caches and gains more (3x3 forward -3 %, weight gradient -1 %) than the pass loses
+// (bn_act +5 %) -- step 6.75 -> 6.69 ms, same-box A/B of the four combinations.
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 template <bool NT>
 __device__ __forceinline__ uint4 ld16(const bf16_t *p) {
@@ -156,7 +159,7 @@ __global__ void bn_inference_coef_kernel(const float *__restrict__ gb, const flo
 // A lane keeps its channel group for all of its pixels, so the 16 coefficients
 // live in registers.  A workgroup owns `ppb` consecutive pixels (a contiguous piece of the tensor when the
 // pixel stride equals the channel count).
-template <int ACT, bool NT>
+template <int ACT, int NT>  // NT bit 0: non-temporal loads, bit 1: non-temporal stores
 __global__ __launch_bounds__(256) void bn_act_kernel(const bf16_t *__restrict__ z, int z_ld, bf16_t *__restrict__ y,
                                                      int y_ld, const ChanFwd *__restrict__ cf, int CG, int PL,
                                                      i64 pixels, i64 ppb) {
@@ -187,11 +190,11 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const bf16_t *__restrict__ 
   for (; p + 3 * PL < p1; p += 4 * PL) {
     uint4 in[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) in[u] = ld16<NT>(z + (p + u * PL) * z_ld + cg * 8);
+    for (int u = 0; u < 4; ++u) in[u] = ld16<(NT & 1) != 0>(z + (p + u * PL) * z_ld + cg * 8);
 #pragma unroll
-    for (int u = 0; u < 4; ++u) st16<NT>(y + (p + u * PL) * y_ld + cg * 8, apply(in[u]));
+    for (int u = 0; u < 4; ++u) st16<(NT & 2) != 0>(y + (p + u * PL) * y_ld + cg * 8, apply(in[u]));
   }
-  for (; p < p1; p += PL) st16<NT>(y + p * y_ld + cg * 8, apply(ld16<NT>(z + p * z_ld + cg * 8)));
+  for (; p < p1; p += PL) st16<(NT & 2) != 0>(y + p * y_ld + cg * 8, apply(ld16<(NT & 1) != 0>(z + p * z_ld + cg * 8)));
 }
 
 // ---- backward -------------------------------------------------------------------
@@ -301,7 +304,7 @@ __global__ __launch_bounds__(256) void bn_finalize_bwd_kernel(const T *__restric
 }
 
 // pass 2: dz = c0*(g - k1 - xhat*k2) (bf16) and, with BIAS, per-block sums of dz (bias gradient)
-template <int ACT, bool BIAS, bool NT>
+template <int ACT, bool BIAS, int NT>  // NT bit 0: non-temporal loads, bit 1: non-temporal stores
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16_t *__restrict__ dy1, int ld1,
                                                            const bf16_t *__restrict__ dy2, int ld2,
                                                            const bf16_t *__restrict__ z, int z_ld,
@@ -358,17 +361,17 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16_t *__restr
       uint4 r1[U], r2[U], rz[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        r1[u] = ld16<NT>(dy1 + (p + u * PL) * ld1 + cg * 8);
-        rz[u] = ld16<NT>(z + (p + u * PL) * z_ld + cg * 8);
-        r2[u] = dy2 ? ld16<NT>(dy2 + (p + u * PL) * ld2 + cg * 8) : zero4;
+        r1[u] = ld16<(NT & 1) != 0>(dy1 + (p + u * PL) * ld1 + cg * 8);
+        rz[u] = ld16<(NT & 1) != 0>(z + (p + u * PL) * z_ld + cg * 8);
+        r2[u] = dy2 ? ld16<(NT & 1) != 0>(dy2 + (p + u * PL) * ld2 + cg * 8) : zero4;
       }
 #pragma unroll
-      for (int u = 0; u < U; ++u) st16<NT>(dz + (p + u * PL) * dz_ld + cg * 8, apply(r1[u], r2[u], rz[u]));
+      for (int u = 0; u < U; ++u) st16<(NT & 2) != 0>(dz + (p + u * PL) * dz_ld + cg * 8, apply(r1[u], r2[u], rz[u]));
     }
     for (; p < p1; p += PL)
-      st16<NT>(dz + p * dz_ld + cg * 8, apply(ld16<NT>(dy1 + p * ld1 + cg * 8),
-                                              dy2 ? ld16<NT>(dy2 + p * ld2 + cg * 8) : zero4,
-                                              ld16<NT>(z + p * z_ld + cg * 8)));
+      st16<(NT & 2) != 0>(dz + p * dz_ld + cg * 8, apply(ld16<(NT & 1) != 0>(dy1 + p * ld1 + cg * 8),
+                                              dy2 ? ld16<(NT & 1) != 0>(dy2 + p * ld2 + cg * 8) : zero4,
+                                              ld16<(NT & 1) != 0>(z + p * z_ld + cg * 8)));
     if (BIAS) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) red[(pl * CG + cg) * 8 + j] = s[j];
@@ -516,7 +519,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_pool_kernel(const bf16_t *__
           out[j] = b[j].c0 * (g[k][j] - b[j].k1 - xh * b[j].k2);
         }
         const uint4 packed = pack8(out);
-        st16<NT>(dz + (pix + (k >> 1) * (i64)ps.W + (k & 1)) * dz_ld + cg * 8, packed);
+        st16<false>(dz + (pix + (k >> 1) * (i64)ps.W + (k & 1)) * dz_ld + cg * 8, packed);
         if (BIAS) {
           float r[8];
           unpack8(packed, r);
@@ -645,7 +648,7 @@ __global__ __launch_bounds__(256) void bn_act_pool_kernel(const bf16_t *__restri
         r[j] = a;
       }
       const uint4 packed = pack8(r);
-      st16<NT>(yq + (i64)(k >> 1) * W * y_ld + (k & 1) * y_ld, packed);
+      st16<false>(yq + (i64)(k >> 1) * W * y_ld + (k & 1) * y_ld, packed);
       unpack8(packed, v[k]);
     }
     float m[8];
@@ -799,6 +802,10 @@ bool stream_nontemporal(double bytes) {
   static const double min_bytes = getenv("UNET_LAB_BN_NT_BYTES") ? atof(getenv("UNET_LAB_BN_NT_BYTES")) : 32e6;
   return bytes >= min_bytes;
 }
+int apply_nt_mask() {  // bn_bwd_apply: 3 = loads and stores non-temporal, 1 = loads only (laboratory switch)
+  static const int m = getenv("UNET_LAB_BN_APPLY_NT_MASK") ? atoi(getenv("UNET_LAB_BN_APPLY_NT_MASK")) : 1;
+  return m == 1 ? 1 : (m == 0 ? 0 : 3);
+}
 int stream_trips() {  // main-loop trips per workgroup of the streaming passes (UNET_LAB_BN_TRIPS: laboratory switch)
   static const int t = [] {
     const char *e = getenv("UNET_LAB_BN_TRIPS");
@@ -861,15 +868,19 @@ int unet_bn_act_bf16(const uint16_t *z, int z_ld, uint16_t *y, int y_ld, const f
 #define ACT_LAUNCH(ACT_, NT_)                                                                                   \
   hipLaunchKernelGGL((bn_act_kernel<ACT_, NT_>), grid, dim3(256), 0, as_stream(s), z, z_ld, y, y_ld, cf, pl.CG, \
                      pl.PL, (i64)pixels, pl.ppb)
-  if (stream_nontemporal(bytes)) {
-    if (act == 0) ACT_LAUNCH(0, true);
-    else if (act == 1) ACT_LAUNCH(1, true);
-    else ACT_LAUNCH(2, true);
-  } else {
-    if (act == 0) ACT_LAUNCH(0, false);
-    else if (act == 1) ACT_LAUNCH(1, false);
-    else ACT_LAUNCH(2, false);
-  }
+  static const int lab_mask = getenv("UNET_LAB_BN_ACT_NT_MASK") ? atoi(getenv("UNET_LAB_BN_ACT_NT_MASK")) : 1;  // laboratory switch
+  const int mask = stream_nontemporal(bytes) ? lab_mask : 0;
+#define ACT_DISPATCH(NT_)                \
+  do {                                   \
+    if (act == 0) ACT_LAUNCH(0, NT_);    \
+    else if (act == 1) ACT_LAUNCH(1, NT_); \
+    else ACT_LAUNCH(2, NT_);             \
+  } while (0)
+  if (mask == 3) ACT_DISPATCH(3);
+  else if (mask == 2) ACT_DISPATCH(2);
+  else if (mask == 1) ACT_DISPATCH(1);
+  else ACT_DISPATCH(0);
+#undef ACT_DISPATCH
 #undef ACT_LAUNCH
   UNET_LAUNCH_CHECK("bn_act_kernel");
   return UNET_OK;
@@ -900,7 +911,7 @@ int unet_bn_act_backward_bf16(const uint16_t *dy1, int ld1, const uint16_t *dy2,
   const size_t lds1 = sizeof(float) * (size_t)pl.PL * pl.CG * 16, lds2 = sizeof(float) * (size_t)pl.PL * pl.CG * 8;
   const double elems = (double)pixels * CoP;
   const RedPlan ps = plan_stream(CoP, pixels, 4, stream_trips());  // the apply pass when it writes no partials
-  const bool nt = stream_nontemporal(2.0 * elems * (dy2 ? 4.0 : 3.0));
+  const int nt = stream_nontemporal(2.0 * elems * (dy2 ? 4.0 : 3.0)) ? apply_nt_mask() : 0;
 #define BWD_LAUNCH(ACT_)                                                                                            \
   do {                                                                                                              \
     {                                                                                                               \
@@ -915,15 +926,19 @@ int unet_bn_act_backward_bf16(const uint16_t *dy1, int ld1, const uint16_t *dy2,
     {                                                                                                               \
       ProfScope prof(PROF_BN_BWD_APPLY_BF16, 0, 2.0 * elems * (dy2 ? 4.0 : 3.0), as_stream(s));                     \
       if (grad_bias)                                                                                               \
-        hipLaunchKernelGGL((bn_bwd_apply_kernel<ACT_, true, false>), dim3(pl.blocks), dim3(256), lds2, as_stream(s), \
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<ACT_, true, 0>), dim3(pl.blocks), dim3(256), lds2, as_stream(s), \
                            dy1, ld1, dy2, ld2, z, z_ld, cf, (const ChanBwd *)cb, dz, dz_ld, pl.CG, pl.PL,          \
                            (i64)pixels, pl.ppb, bias_part, CoP);                                                    \
-      else if (nt)                                                                                                  \
-        hipLaunchKernelGGL((bn_bwd_apply_kernel<ACT_, false, true>), dim3(ps.blocks), dim3(256), 0, as_stream(s),   \
+      else if (nt == 3)                                                                                             \
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<ACT_, false, 3>), dim3(ps.blocks), dim3(256), 0, as_stream(s),      \
+                           dy1, ld1, dy2, ld2, z, z_ld, cf, (const ChanBwd *)cb, dz, dz_ld, ps.CG, ps.PL,          \
+                           (i64)pixels, ps.ppb, (float *)nullptr, CoP);                                             \
+      else if (nt == 1)                                                                                             \
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<ACT_, false, 1>), dim3(ps.blocks), dim3(256), 0, as_stream(s),      \
                            dy1, ld1, dy2, ld2, z, z_ld, cf, (const ChanBwd *)cb, dz, dz_ld, ps.CG, ps.PL,          \
                            (i64)pixels, ps.ppb, (float *)nullptr, CoP);                                             \
       else                                                                                                          \
-        hipLaunchKernelGGL((bn_bwd_apply_kernel<ACT_, false, false>), dim3(ps.blocks), dim3(256), 0, as_stream(s),  \
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<ACT_, false, 0>), dim3(ps.blocks), dim3(256), 0, as_stream(s),      \
                            dy1, ld1, dy2, ld2, z, z_ld, cf, (const ChanBwd *)cb, dz, dz_ld, ps.CG, ps.PL,          \
                            (i64)pixels, ps.ppb, (float *)nullptr, CoP);                                             \
     }                                                                                                               \
@@ -1044,16 +1059,21 @@ int unet_bn_act_backward_from_partials_bf16(const uint16_t *dy, int dy_ld, const
   {
     ProfScope prof(PROF_BN_BWD_APPLY_BF16, 0, 2.0 * (double)pixels * CoP * 3.0, as_stream(s));
     const RedPlan ps = plan_stream(CoP, pixels, 4, stream_trips());
+    const int nt = stream_nontemporal(2.0 * (double)pixels * CoP * 3.0) ? apply_nt_mask() : 0;
     if (grad_bias)
-      hipLaunchKernelGGL((bn_bwd_apply_kernel<0, true, false>), dim3(pl.blocks), dim3(256),
+      hipLaunchKernelGGL((bn_bwd_apply_kernel<0, true, 0>), dim3(pl.blocks), dim3(256),
                          sizeof(float) * (size_t)pl.PL * pl.CG * 8, as_stream(s), dy, dy_ld, (const bf16_t *)nullptr, 0, z,
                          z_ld, cf, (const ChanBwd *)cb, dz, dz_ld, pl.CG, pl.PL, (i64)pixels, pl.ppb, bias_part, CoP);
-    else if (stream_nontemporal(2.0 * (double)pixels * CoP * 3.0))
-      hipLaunchKernelGGL((bn_bwd_apply_kernel<0, false, true>), dim3(ps.blocks), dim3(256), 0, as_stream(s), dy, dy_ld,
+    else if (nt == 3)
+      hipLaunchKernelGGL((bn_bwd_apply_kernel<0, false, 3>), dim3(ps.blocks), dim3(256), 0, as_stream(s), dy, dy_ld,
+                         (const bf16_t *)nullptr, 0, z, z_ld, cf, (const ChanBwd *)cb, dz, dz_ld, ps.CG, ps.PL,
+                         (i64)pixels, ps.ppb, (float *)nullptr, CoP);
+    else if (nt == 1)
+      hipLaunchKernelGGL((bn_bwd_apply_kernel<0, false, 1>), dim3(ps.blocks), dim3(256), 0, as_stream(s), dy, dy_ld,
                          (const bf16_t *)nullptr, 0, z, z_ld, cf, (const ChanBwd *)cb, dz, dz_ld, ps.CG, ps.PL,
                          (i64)pixels, ps.ppb, (float *)nullptr, CoP);
     else
-      hipLaunchKernelGGL((bn_bwd_apply_kernel<0, false, false>), dim3(ps.blocks), dim3(256), 0, as_stream(s), dy, dy_ld,
+      hipLaunchKernelGGL((bn_bwd_apply_kernel<0, false, 0>), dim3(ps.blocks), dim3(256), 0, as_stream(s), dy, dy_ld,
                          (const bf16_t *)nullptr, 0, z, z_ld, cf, (const ChanBwd *)cb, dz, dz_ld, ps.CG, ps.PL,
                          (i64)pixels, ps.ppb, (float *)nullptr, CoP);
   }
