@@ -61,6 +61,7 @@ struct Args {
   int co_valid;
   int accumulate;
   int nt_store;         // 1: the output is stored non-temporal (large tensors that no cache holds until they are read)
+  int reverse;          // 1: the units are walked from the last to the first (the input's most recently written end first)
   // BRED: the output is the gradient of a BN + ReLU layer's output; bz = that layer's pre-BN tensor,
   // bcf its per-channel records {a, b, mean, 1/sqrt(var+eps)}; stats receives (sum g*xhat, sum g),
   // g = out * relu'(a*z + b).  Channels below bred_c0 take no part; bz, bcf and stats are indexed by
@@ -178,7 +179,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pipe_kernel(const Args a) {
   const auto wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(a.wt), 0, slab_bytes * a.nk, 0x00020000);
 
   auto unit_coords = [&](int it, int &n, int &y0, int &x0) {
-    const int u = wgi + it * nwg;
+    int u = wgi + it * nwg;
+    if (a.reverse) u = a.units - 1 - u;
     n = u / tpi;
     const int t = u - n * tpi, ty = t / a.tilesX;
     y0 = ty * TH;

@@ -524,6 +524,11 @@ int launch_pipe_from(const ConvArgs &c, hipStream_t s) {
     static const double lab_bytes = getenv("UNET_LAB_CONV_NT_BYTES") ? atof(getenv("UNET_LAB_CONV_NT_BYTES")) : -1;
     const double out_bytes = 2.0 * c.N * c.Ho * c.Wo * c.CoP;
     const bool data_gradient = c.bz || (!c.stats && !c.affine);
+    // The tiles are walked from the last image to the first: the pass that produced the input wrote it in
+    // ascending order, so its end is what the caches still hold, and the pass that reads the output next
+    // (ascending again) starts with what this kernel wrote last.  Step -0.4 %.  UNET_LAB_CONV_REVERSE=0: laboratory switch.
+    static const int lab_reverse = getenv("UNET_LAB_CONV_REVERSE") ? atoi(getenv("UNET_LAB_CONV_REVERSE")) : 1;
+    a.reverse = lab_reverse != 0;
     a.nt_store = lab_bytes >= 0 ? (lab_bytes > 0 && out_bytes >= lab_bytes) : (data_gradient && out_bytes >= 60e6);
   }
   a.bz = c.bz; a.bz_ld = c.bz_ld; a.bcf = c.bcf; a.bred_c0 = c.bred_c0; a.affine = c.affine;
