@@ -522,6 +522,7 @@ int launch_pipe_from(const ConvArgs &c, hipStream_t s) {
     // normalisation pass that reads them right after the convolution was 3-6 % slower behind non-temporal stores.
     // UNET_LAB_CONV_NT_BYTES: laboratory switch (threshold in bytes for every launch; 0 = never).
     static const double lab_bytes = getenv("UNET_LAB_CONV_NT_BYTES") ? atof(getenv("UNET_LAB_CONV_NT_BYTES")) : -1;
+    static const double dgrad_bytes = getenv("UNET_LAB_CONV_NT_DGRAD_BYTES") ? atof(getenv("UNET_LAB_CONV_NT_DGRAD_BYTES")) : 60e6;
     const double out_bytes = 2.0 * c.N * c.Ho * c.Wo * c.CoP;
     const bool data_gradient = c.bz || (!c.stats && !c.affine);
     // The tiles are walked from the last image to the first: the pass that produced the input wrote it in
@@ -529,7 +530,7 @@ int launch_pipe_from(const ConvArgs &c, hipStream_t s) {
     // (ascending again) starts with what this kernel wrote last.  Step -0.4 %.  UNET_LAB_CONV_REVERSE=0: laboratory switch.
     static const int lab_reverse = getenv("UNET_LAB_CONV_REVERSE") ? atoi(getenv("UNET_LAB_CONV_REVERSE")) : 1;
     a.reverse = lab_reverse != 0;
-    a.nt_store = lab_bytes >= 0 ? (lab_bytes > 0 && out_bytes >= lab_bytes) : (data_gradient && out_bytes >= 60e6);
+    a.nt_store = lab_bytes >= 0 ? (lab_bytes > 0 && out_bytes >= lab_bytes) : (data_gradient && out_bytes >= dgrad_bytes);
   }
   a.bz = c.bz; a.bz_ld = c.bz_ld; a.bcf = c.bcf; a.bred_c0 = c.bred_c0; a.affine = c.affine;
   const int grid = pipe::plan_grid(c.N, c.Ho, c.Wo, c.CoP);
