@@ -9,7 +9,7 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 if steps == 0:  # only the last full training step: the launches between the last two optimiser kernels
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    idx = [i for i, r in enumerate(rows) if "adam_kernel" in r["Kernel_Name"]]
+    idx = [i for i, r in enumerate(rows) if "::adam_" in r["Kernel_Name"]]
     rows = rows[idx[-2] + 1:idx[-1] + 1]
     steps = 1
 filt = re.compile(sys.argv[3]) if len(sys.argv) > 3 else None
