@@ -174,6 +174,44 @@ def test_conv3x3_wgrad_long_pixel_slices(G, capi, cfg):
     np.testing.assert_array_equal(G.host(again).reshape(ci, co, 3, 3), got)
 
 
+@pytest.mark.parametrize("hw", [(256, 256), (16, 16)])
+def test_pipelined_kernel_is_bit_identical_to_the_general_kernel_at_training_sizes(G, capi, hw):
+    """The two 3x3 kernels on the same operands, forward (with statistics) and data gradient: every output
+    bit equal.  At 256 x 256 with batch 8 the data gradient is large enough (67 MB) for the pipelined kernel's
+    non-temporal stores, and every workgroup walks several tiles in reversed order; 16 x 16 with 1024 channels
+    is the 16-row tile variant at the size the benchmark graph uses it."""
+    h, w = hw
+    n, ci, co = (8, 64, 64) if h == 256 else (16, 512, 1024)
+    gen = torch.Generator(device="cpu").manual_seed(h)
+    x = torch.randn((n, h, w, ci), generator=gen).to(G.DEV).bfloat16()
+    dy = torch.randn((n, h, w, co), generator=gen).to(G.DEV).bfloat16()
+    wt = (torch.randn(ci * co * 9, generator=gen) / np.sqrt(9 * ci)).numpy().astype(np.float32)
+    fwd, bwd = pack(G, capi, wt, ci, co, 3)
+    bias = G.dev((np.arange(co) % 7 - 3).astype(np.float32) * 0.1)
+    lib = capi.lib()
+
+    def run():
+        rows = lib.unet_conv3x3_stat_rows(n, h, w, ci, co)
+        out = torch.full((n, h, w, co), float("nan"), dtype=torch.bfloat16, device=G.DEV)
+        stats = G.empty((rows, co, 2))
+        capi.unet_conv3x3_bf16(G.p(x), ci, G.p(fwd), G.p(bias), co, G.p(out), co, G.p(stats), n, h, w, ci, co, 0, None)
+        dx = torch.full((n, h, w, ci), float("nan"), dtype=torch.bfloat16, device=G.DEV)
+        capi.unet_conv3x3_bf16(G.p(dy), co, G.p(bwd), None, 0, G.p(dx), ci, None, n, h, w, co, ci, 0, None)
+        torch.cuda.synchronize()
+        return out, dx, stats.double().sum(dim=0)
+
+    old = lib.unet_conv3x3_pipeline_min_units(128)        # the threshold of training runs: the pipelined kernel
+    try:
+        out_p, dx_p, st_p = run()
+        lib.unet_conv3x3_pipeline_min_units(1 << 30)      # nothing is large enough: the general kernel
+        out_g, dx_g, st_g = run()
+    finally:
+        lib.unet_conv3x3_pipeline_min_units(old)
+    assert torch.equal(out_p.view(torch.int16), out_g.view(torch.int16))
+    assert torch.equal(dx_p.view(torch.int16), dx_g.view(torch.int16))
+    assert torch.allclose(st_p, st_g, rtol=1e-5, atol=1e-3 * float(st_g.abs().max()))
+
+
 def test_conv3x3_reads_channel_slices(G, capi, oracle):
     """Input and output tensors that are channel slices of wider buffers
     (pixel stride > channel count): the zero-copy concat layout."""
