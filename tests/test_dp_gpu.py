@@ -130,7 +130,7 @@ def test_two_ranks_on_one_gpu_match_single_process():
     assert np.isfinite(p1_a).all() and not np.array_equal(p1_a, p0_a)
 
 
-def _rccl_rank(port, q, sync_bn):
+def _rccl_rank(port, q, sync_bn, break_comm=False):
     try:
         os.environ["MASTER_ADDR"] = "127.0.0.1"
         os.environ["MASTER_PORT"] = str(port)
@@ -151,8 +151,15 @@ def _rccl_rank(port, q, sync_bn):
         want_g, want_p = np.asarray(plain.get_gradients()), np.asarray(plain.get_parameters())
         net = _make_net(64 << 10)
         net.set_parameters(p0)
+        if break_comm:   # the library's communicator cannot be created: torch.distributed takes over
+            def no_comm(*args, **kwargs):
+                raise RuntimeError("simulated: cannot open librccl.so.1")
+            dp.init_comm = no_comm
         trainer = dp.DataParallel(net, dev, bucket_bytes=64 << 10, force_collectives=True, sync_bn=sync_bn)
-        assert trainer.native and trainer.comm is not None
+        if break_comm:
+            assert not trainer.native and trainer.comm is None and trainer.torch_device_reduce
+        else:
+            assert trainer.native and trainer.comm is not None
         trainer.broadcast_parameters()
         for _ in range(2):   # twice: the second pass reuses the bucket events and the communication stream
             net.set_parameters(p0)
@@ -169,14 +176,14 @@ def _rccl_rank(port, q, sync_bn):
         q.put((False, traceback.format_exc() + str(e)))
 
 
-def _run_one_rank(sync_bn):
+def _run_one_rank(sync_bn, break_comm=False):
     import torch.multiprocessing as mp
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    p = ctx.Process(target=_rccl_rank, args=(port, q, sync_bn))
+    p = ctx.Process(target=_rccl_rank, args=(port, q, sync_bn, break_comm))
     p.start()
     ok, payload = q.get(timeout=240)
     p.join(timeout=60)
@@ -191,6 +198,14 @@ def test_rccl_transport_one_rank():
     want_g, got_g, want_p, got_p, nb = _run_one_rank(False)
     assert nb >= 3
     # the second step starts from the first step's Adam state, so compare gradients (state-free)
+    assert np.array_equal(want_g, got_g)
+    assert np.isfinite(got_p).all()
+
+
+def test_torch_distributed_takes_over_when_the_library_communicator_fails():
+    """unet_comm_init_rank failing (simulated) must not end a data-parallel run: DataParallel then reduces the
+    gradient buckets with torch.distributed on the device buffers; on one rank the step equals the plain one."""
+    want_g, got_g, want_p, got_p, nb = _run_one_rank(False, break_comm=True)
     assert np.array_equal(want_g, got_g)
     assert np.isfinite(got_p).all()
 

@@ -92,16 +92,28 @@ class DataParallel:
             sync_bn = os.environ.get("UNET_SYNC_BN", "0") not in ("", "0")
         self.sync_bn = bool(sync_bn)
         self.comm = None
+        self.torch_device_reduce = False
         active = self.world > 1 or self.force
         # RCCL needs one GPU per rank; "gloo" groups (CPU tests, ranks sharing a GPU) stage through the host
         self.native = active and dist.get_backend(group) == "nccl"
         if self.native:
             if self.force:
                 os.environ["UNET_COMM_FORCE"] = "1"   # run the collectives even in a one-rank communicator
-            self.comm = init_comm(capi, group, device)
-            net.set_comm(self.comm.value)
-            if self.sync_bn:
-                capi.unet_bn_set_sync(self.comm)
+            try:
+                self.comm = init_comm(capi, group, device)
+            except RuntimeError as e:
+                # the library's own communicator could not be set up (e.g. no librccl.so.1 on the loader path):
+                # torch.distributed's collectives on the same device buffers do the same reduction, without the
+                # overlap with backward.  Every rank sees the same failure, so every rank takes this path.
+                if self.sync_bn:
+                    raise
+                print(f"unet_amd.dp: {e}; reducing gradients through torch.distributed instead", flush=True)
+                self.native = False
+                self.torch_device_reduce = True
+            else:
+                net.set_comm(self.comm.value)
+                if self.sync_bn:
+                    capi.unet_bn_set_sync(self.comm)
         elif self.sync_bn and active:
             raise RuntimeError("sync_bn needs the RCCL transport (torch.distributed backend 'nccl')")
 
@@ -118,6 +130,11 @@ class DataParallel:
         if self.native:
             self.net.broadcast_state(src)
             self.net.synchronize()
+        elif self.world > 1 and self.torch_device_reduce:
+            self.net.synchronize()
+            dist.broadcast(self.params, src, group=self.group)
+            torch.cuda.synchronize(self.device)
+            self.net.parameters_changed()
         elif self.world > 1:
             self.net.synchronize()
             host = self.params.cpu()
@@ -130,6 +147,12 @@ class DataParallel:
         """Host-staged transport only (the native one reduces inside backward): averages the gradient
         buffer over the ranks, bucket by bucket, each bucket as soon as backward has finished it."""
         if self.native or self.world == 1:
+            return
+        if self.torch_device_reduce:   # RCCL through torch.distributed, on the device buffers themselves
+            self.net.synchronize()
+            for off, cnt, _ in self.buckets:
+                dist.all_reduce(self.grads[off:off + cnt], op=dist.ReduceOp.AVG, group=self.group)
+            torch.cuda.synchronize(self.device)
             return
         for off, cnt, ev in self.buckets:
             if ev:
