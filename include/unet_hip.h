@@ -382,6 +382,10 @@ int unet_comm_init_rank(unet_comm_t *comm, const void *id_host, int world_size, 
 int unet_comm_destroy(unet_comm_t comm);
 int unet_comm_size(unet_comm_t comm, int *world_size, int *rank);
 int unet_allreduce_begin(unet_comm_t comm, float *data, int64_t count, unet_event_t ready);
+/* on != 0: unet_allreduce_begin sends its buckets as bf16 (rounded to nearest even on the communication stream,
+ * averaged in bf16, widened back into `data`): half the bytes on the links and half the time the collective's
+ * kernels share the GPU with backward, at bf16 precision of the averaged gradients.  Off by default. */
+int unet_comm_set_bf16_gradients(unet_comm_t comm, int on);
 int unet_allreduce_wait(unet_comm_t comm, unet_stream_t stream);
 int unet_allreduce_sum_f32(unet_comm_t comm, float *data, int64_t count, unet_stream_t stream);
 int unet_broadcast_f32(unet_comm_t comm, float *data, int64_t count, int root, unet_stream_t stream);

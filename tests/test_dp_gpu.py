@@ -130,7 +130,7 @@ def test_two_ranks_on_one_gpu_match_single_process():
     assert np.isfinite(p1_a).all() and not np.array_equal(p1_a, p0_a)
 
 
-def _rccl_rank(port, q, sync_bn, break_comm=False):
+def _rccl_rank(port, q, sync_bn, break_comm=False, bf16_gradients=False):
     try:
         os.environ["MASTER_ADDR"] = "127.0.0.1"
         os.environ["MASTER_PORT"] = str(port)
@@ -155,7 +155,8 @@ def _rccl_rank(port, q, sync_bn, break_comm=False):
             def no_comm(*args, **kwargs):
                 raise RuntimeError("simulated: cannot open librccl.so.1")
             dp.init_comm = no_comm
-        trainer = dp.DataParallel(net, dev, bucket_bytes=64 << 10, force_collectives=True, sync_bn=sync_bn)
+        trainer = dp.DataParallel(net, dev, bucket_bytes=64 << 10, force_collectives=True, sync_bn=sync_bn,
+                                  bf16_gradients=bf16_gradients)
         if break_comm:
             assert not trainer.native and trainer.comm is None and trainer.torch_device_reduce
         else:
@@ -176,14 +177,14 @@ def _rccl_rank(port, q, sync_bn, break_comm=False):
         q.put((False, traceback.format_exc() + str(e)))
 
 
-def _run_one_rank(sync_bn, break_comm=False):
+def _run_one_rank(sync_bn, break_comm=False, bf16_gradients=False):
     import torch.multiprocessing as mp
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    p = ctx.Process(target=_rccl_rank, args=(port, q, sync_bn, break_comm))
+    p = ctx.Process(target=_rccl_rank, args=(port, q, sync_bn, break_comm, bf16_gradients))
     p.start()
     ok, payload = q.get(timeout=240)
     p.join(timeout=60)
@@ -207,6 +208,18 @@ def test_torch_distributed_takes_over_when_the_library_communicator_fails():
     gradient buckets with torch.distributed on the device buffers; on one rank the step equals the plain one."""
     want_g, got_g, want_p, got_p, nb = _run_one_rank(False, break_comm=True)
     assert np.array_equal(want_g, got_g)
+    assert np.isfinite(got_p).all()
+
+
+def test_bf16_gradient_transport_one_rank():
+    """unet_comm_set_bf16_gradients: every bucket is rounded to bf16, averaged by RCCL in bf16 and widened back.
+    On one rank the mean is the identity, so the gradients must come out as the plain ones rounded to bf16
+    (round to nearest even), bit for bit."""
+    import torch
+    want_g, got_g, want_p, got_p, nb = _run_one_rank(False, bf16_gradients=True)
+    rounded = torch.from_numpy(want_g).bfloat16().float().numpy()
+    assert np.array_equal(rounded, got_g)
+    assert not np.array_equal(want_g, got_g)
     assert np.isfinite(got_p).all()
 
 

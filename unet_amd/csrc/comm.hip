@@ -69,7 +69,22 @@ struct Comm {
   hipStream_t stream = nullptr;  // the communication stream
   hipEvent_t done = nullptr;     // recorded after the last collective enqueued on it
   bool pending = false;
+  bool bf16_gradients = false;   // unet_comm_set_bf16_gradients: buckets travel as bf16
+  uint16_t *stage = nullptr;     // bf16 copy of the bucket in flight (grow-only; the stream serialises its uses)
+  size_t stage_elems = 0;
 };
+
+// fp32 <-> bf16 (round to nearest even) over a gradient bucket, 4 values per lane
+__global__ __launch_bounds__(256) void grad_to_bf16_kernel(const float *__restrict__ in, uint16_t *__restrict__ out, i64 n) {
+  for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (i64)gridDim.x * blockDim.x) {
+    const __bf16 h = (__bf16)in[i];
+    out[i] = __builtin_bit_cast(unsigned short, h);
+  }
+}
+__global__ __launch_bounds__(256) void grad_from_bf16_kernel(const uint16_t *__restrict__ in, float *__restrict__ out, i64 n) {
+  for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (i64)gridDim.x * blockDim.x)
+    out[i] = __uint_as_float((uint32_t)in[i] << 16);
+}
 
 // The communicator batch-norm launchers synchronise their statistics over (NULL = per-rank statistics).
 Comm *g_bn_sync = nullptr;
@@ -138,6 +153,7 @@ int unet_comm_destroy(unet_comm_t comm) {
   if (!c) return UNET_OK;
   if (g_bn_sync == c) g_bn_sync = nullptr;
   (void)hipStreamSynchronize(c->stream);
+  if (c->stage) (void)hipFree(c->stage);
   if (c->nccl) (void)g_rccl.CommDestroy(c->nccl);
   (void)hipStreamDestroy(c->stream);
   (void)hipEventDestroy(c->done);
@@ -157,8 +173,34 @@ int unet_allreduce_begin(unet_comm_t comm, float *data, int64_t count, unet_even
   Comm *c = static_cast<Comm *>(comm);
   UNET_REQUIRE(c && data && count > 0, "unet_allreduce_begin: bad argument");
   if (ready) UNET_HIP_TRY(hipStreamWaitEvent(c->stream, (hipEvent_t)ready, 0));
-  UNET_NCCL_TRY(g_rccl.AllReduce(data, data, (size_t)count, ncclFloat32, ncclAvg, c->nccl, c->stream));
+  if (c->bf16_gradients) {
+    // half the bytes on the links and half the time the collective's kernels stay resident: the bucket is
+    // rounded to bf16, averaged in bf16 and widened again, all on the communication stream
+    if (c->stage_elems < (size_t)count) {
+      UNET_HIP_TRY(hipStreamSynchronize(c->stream));  // earlier buckets may still use the old buffer
+      if (c->stage) UNET_HIP_TRY(hipFree(c->stage));
+      c->stage = nullptr;
+      c->stage_elems = 0;
+      UNET_HIP_TRY(hipMalloc((void **)&c->stage, sizeof(uint16_t) * (size_t)count));
+      c->stage_elems = (size_t)count;
+    }
+    const unsigned blocks = (unsigned)((count + 1023) / 1024 < 4096 ? (count + 1023) / 1024 : 4096);
+    hipLaunchKernelGGL(grad_to_bf16_kernel, dim3(blocks), dim3(256), 0, c->stream, (const float *)data, c->stage, (i64)count);
+    UNET_LAUNCH_CHECK("grad_to_bf16_kernel");
+    UNET_NCCL_TRY(g_rccl.AllReduce(c->stage, c->stage, (size_t)count, ncclBfloat16, ncclAvg, c->nccl, c->stream));
+    hipLaunchKernelGGL(grad_from_bf16_kernel, dim3(blocks), dim3(256), 0, c->stream, (const uint16_t *)c->stage, data, (i64)count);
+    UNET_LAUNCH_CHECK("grad_from_bf16_kernel");
+  } else {
+    UNET_NCCL_TRY(g_rccl.AllReduce(data, data, (size_t)count, ncclFloat32, ncclAvg, c->nccl, c->stream));
+  }
   c->pending = true;
+  return UNET_OK;
+}
+
+int unet_comm_set_bf16_gradients(unet_comm_t comm, int on) {
+  Comm *c = static_cast<Comm *>(comm);
+  UNET_REQUIRE(c, "unet_comm_set_bf16_gradients: NULL communicator");
+  c->bf16_gradients = on != 0;
   return UNET_OK;
 }
 

@@ -77,7 +77,8 @@ def init_comm(capi, group=None, device=None):
 class DataParallel:
     """Wraps a created neural_net.NeuralNet for synchronous data-parallel training."""
 
-    def __init__(self, net, device, bucket_bytes=16 << 20, group=None, force_collectives=False, sync_bn=None):
+    def __init__(self, net, device, bucket_bytes=16 << 20, group=None, force_collectives=False, sync_bn=None,
+                 bf16_gradients=None):
         from unet_amd import capi
         self.net, self.device, self.group, self._capi = net, device, group, capi
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -114,6 +115,10 @@ class DataParallel:
                 net.set_comm(self.comm.value)
                 if self.sync_bn:
                     capi.unet_bn_set_sync(self.comm)
+                if bf16_gradients is None:
+                    bf16_gradients = os.environ.get("UNET_GRAD_BF16", "0") not in ("", "0")
+                if bf16_gradients:   # the buckets travel as bf16 (half the traffic; native transport only)
+                    capi.unet_comm_set_bf16_gradients(self.comm, 1)
         elif self.sync_bn and active:
             raise RuntimeError("sync_bn needs the RCCL transport (torch.distributed backend 'nccl')")
 
