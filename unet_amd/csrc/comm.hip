@@ -74,7 +74,7 @@ struct Comm {
   size_t stage_elems = 0;
 };
 
-// fp32 <-> bf16 (round to nearest even) over a gradient bucket, 4 values per lane
+// fp32 <-> bf16 (round to nearest even) over a gradient bucket, grid-stride
 __global__ __launch_bounds__(256) void grad_to_bf16_kernel(const float *__restrict__ in, uint16_t *__restrict__ out, i64 n) {
   for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (i64)gridDim.x * blockDim.x) {
     const __bf16 h = (__bf16)in[i];
