@@ -101,6 +101,20 @@ def test_config1_unet_forward_bf16_inference(nn, graph, inference_case):
     assert_close_bf16_net(got, want, "bf16 inference output", rel_bar=max(2e-2, 0.8e-2 * np.sqrt(23)), guard=False)
 
 
+def test_bf16_inference_of_an_image_does_not_depend_on_the_batch_it_comes_in(nn, graph):
+    """Batch 16 runs the pipelined 3x3 kernel on most layers, batches of 1-4 the general kernel, and launches of
+    few workgroups go out as 32-channel blocks instead of 64: all of them must add in the same order."""
+    rng = np.random.default_rng(33)
+    x = rng.standard_normal((16, 3, H, H)).astype(np.float32)
+    m = (rng.random((16, H, H)) < 0.03).astype(np.float32)
+    net = _make(nn, graph, "bf16")
+    net.train_step(x, m, 1e-3, True)                      # moves the running statistics
+    yb = net.forward(x, True)
+    assert np.isfinite(yb).all() and not np.array_equal(yb[0], yb[15])
+    for lo, hi in ((0, 1), (15, 16), (6, 8), (0, 4), (8, 16)):
+        assert np.array_equal(net.forward(x[lo:hi], True), yb[lo:hi]), (lo, hi)
+
+
 def test_config2_train_step_full_size_properties(nn, graph):
     rng = np.random.default_rng(22)
     n = 16

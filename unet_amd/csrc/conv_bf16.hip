@@ -457,6 +457,15 @@ int launch_conv(const ConvArgs &a, hipStream_t s) {
 
 int launch_pipe_from(const ConvArgs &c, hipStream_t s);
 
+// Launches of at most this many 64-channel workgroups go out as 32-channel blocks (inference forward).
+int narrow_block_workgroups() {
+  static const int v = [] {
+    const char *e = getenv("UNET_LAB_CONV_NARROW_WGS");
+    return e ? atoi(e) : 128;
+  }();
+  return v;
+}
+
 int launch_conv_any(int taps, const ConvArgs &a, hipStream_t s) {
   if (taps == 9 && pipe::eligible(a.N, a.Ho, a.Wo, a.Ci, a.CoP) && !(a.accumulate && a.stats)) return launch_pipe_from(a, s);
   const bool wide = a.CoP % 64 == 0, deep = a.Ci % 64 == 0;
@@ -467,6 +476,13 @@ int launch_conv_any(int taps, const ConvArgs &a, hipStream_t s) {
   const bool mma16 = taps == 9 && wide &&
                      ((a.Ho >= 16 && a.Wo >= 16) || (i64)a.tilesX * ((a.Ho + 15) / 16) * (a.CoP / 64) > 16);
   if (a.affine) {  // inference forward
+    // Few images: a launch of 64-channel blocks would leave most of the device idle (one image of 16 x 16 pixels
+    // and 1024 channels is 16 workgroups), and a workgroup alone on its CU runs at the pace of its own LDS reads
+    // and MFMAs.  Blocks of 32 channels double the workgroups; every output is still added up in the same order.
+    // (Two 32-channel chunks per main-loop trip on top of that measured nothing: the trips are not waiting for
+    // their loads.)
+    if (mma16 && (i64)a.N * a.tilesX * ((a.Ho + 15) / 16) * (a.CoP / 64) <= narrow_block_workgroups())
+      return launch_conv<9, 32, false, 32, 1, true>(a, s);
     if (mma16) return launch_conv<9, 64, false, 32, 1, true>(a, s);
     if (taps == 9) return wide ? launch_conv<9, 64, false, 32, 0, true>(a, s) : launch_conv<9, 32, false, 32, 0, true>(a, s);
     if (wide) return deep ? launch_conv<1, 64, false, 64, 0, true>(a, s) : launch_conv<1, 64, false, 32, 0, true>(a, s);
