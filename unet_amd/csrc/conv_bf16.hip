@@ -485,6 +485,9 @@ int launch_conv_any(int taps, const ConvArgs &a, hipStream_t s) {
       return launch_conv<9, 32, false, 32, 1, true>(a, s);
     if (mma16) return launch_conv<9, 64, false, 32, 1, true>(a, s);
     if (taps == 9) return wide ? launch_conv<9, 64, false, 32, 0, true>(a, s) : launch_conv<9, 32, false, 32, 0, true>(a, s);
+    if (wide && deep && (i64)a.N * a.tilesX * ((a.Ho + 15) / 16) * (a.CoP / 64) * (a.out_phases > 1 ? a.out_phases : 1) <=
+                            narrow_block_workgroups())
+      return launch_conv<1, 32, false, 64, 0, true>(a, s);  // the same ascending sum over the input channels
     if (wide) return deep ? launch_conv<1, 64, false, 64, 0, true>(a, s) : launch_conv<1, 64, false, 32, 0, true>(a, s);
     return launch_conv<1, 32, false, 32, 0, true>(a, s);
   }
