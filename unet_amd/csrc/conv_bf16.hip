@@ -491,6 +491,8 @@ int launch_conv_any(int taps, const ConvArgs &a, hipStream_t s) {
     if (wide) return deep ? launch_conv<1, 64, false, 64, 0, true>(a, s) : launch_conv<1, 64, false, 32, 0, true>(a, s);
     return launch_conv<1, 32, false, 32, 0, true>(a, s);
   }
+  if (mma16 && (i64)a.N * a.tilesX * ((a.Ho + 15) / 16) * (a.CoP / 64) <= narrow_block_workgroups())  // as above
+    return a.bz ? launch_conv<9, 32, true, 32, 1>(a, s) : launch_conv<9, 32, false, 32, 1>(a, s);
   if (mma16) return a.bz ? launch_conv<9, 64, true, 32, 1>(a, s) : launch_conv<9, 64, false, 32, 1>(a, s);
   if (a.bz) {
     if (taps == 9) return wide ? launch_conv<9, 64, true>(a, s) : launch_conv<9, 32, true>(a, s);
