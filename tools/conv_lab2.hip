@@ -122,7 +122,7 @@ int main(int argc, char **argv) {
     a.N = N; a.H = s.H; a.W = s.H; a.nk = s.Ci / 32; a.CoP = s.Co; a.in_ld = s.Ci; a.out_ld = s.Co;
     a.tilesX = (s.H + pipe::TW - 1) / pipe::TW; a.tilesY = (s.H + pipe::TH - 1) / pipe::TH;
     a.units = N * a.tilesX * a.tilesY; a.co_blocks = s.Co / 64; a.co_valid = s.Co;
-    const int grid = pipe::plan_grid(N, s.H, s.H, s.Co, wgs);
+    const int grid = pipe::plan_grid(N, s.H, s.H, s.Co, s.H >= 32 ? 32 : 16, wgs);
     a.xcd_order = (grid % (8 * a.co_blocks) == 0 && !getenv("LAB_NO_XCD")) ? 1 : 0;
     const bool ws = a.nk <= pipe::MAX_WS_CHUNKS;
     auto launch = [&] {
@@ -131,7 +131,7 @@ int main(int argc, char **argv) {
       else
         hipLaunchKernelGGL((pipe::conv3x3_pipe_kernel<false, pipe::EPI_STATS>), dim3(grid), dim3(512), pipe::LDS_BYTES, 0, a);
     };
-    const int tiles16 = unet_conv3x3_stat_tiles(s.H, s.H), rows = pipe::stat_rows(N, s.H, s.H, s.Co, wgs);
+    const int tiles16 = unet_conv3x3_stat_tiles(s.H, s.H), rows = pipe::stat_rows(N, s.H, s.H, s.Co, s.H >= 32 ? 32 : 16, wgs);
     const size_t out_n = (size_t)N * s.H * s.H * s.Co;
     CK(hipMemset(d_out, 0xff, out_n * 2));
     CK(hipMemset(d_stats, 0xff, (size_t)rows * s.Co * 8));

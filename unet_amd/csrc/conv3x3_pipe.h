@@ -446,22 +446,40 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pipe_kernel(const Args a) {
   }
 }
 
-// Launch plan: persistent workgroups, a multiple of the channel-block count, at most one per tile and channel block.
-// th = tile_rows(H): 32-row tiles, 16-row tiles for images of fewer than 32 rows.
-inline int tile_rows(int H) {
+// th = tile_rows(...): 32-row tiles, except 16-row tiles
+//  - for images of fewer than 32 rows;
+//  - where 32-row tiles are fewer than the 256 workgroups a launch can have (small batches, deep levels): twice the
+//    tiles, twice the workgroups;
+//  - for layers whose weights stay resident in LDS (C_in <= 64), where 32-row tiles would leave a workgroup fewer
+//    than small_tiles_below() of them: a persistent workgroup with two tiles spends as long filling and draining
+//    its pipeline as computing, and with resident weights smaller tiles cost only their halo.  (Layers that stream
+//    their weights per tile lose more to the doubled weight traffic than they gain: measured.)
+// Exactly one 32-row tile per workgroup stays as it is.  Both sizes add in the same order.
+inline int small_tiles_below() {  // UNET_LAB_PIPE_SMALL_TILES_BELOW: laboratory switch (tiles per workgroup)
+  static const int v = getenv("UNET_LAB_PIPE_SMALL_TILES_BELOW") ? atoi(getenv("UNET_LAB_PIPE_SMALL_TILES_BELOW")) : 3;
+  return v;
+}
+inline int tile_rows(int N, int H, int W, int CiP, int CoP) {
   static const int forced = getenv("UNET_LAB_PIPE_TILE_ROWS") ? atoi(getenv("UNET_LAB_PIPE_TILE_ROWS")) : 0;  // laboratory switch
   if (forced == 16 || (forced == 32 && H >= 32)) return forced;
-  return H >= 32 ? 32 : 16;
+  if (H < 32) return 16;
+  const long long units32 = (long long)N * ((H + 31) / 32) * ((W + TW - 1) / TW) * (CoP / 64);
+  if (units32 < 256) return 16;
+  if (CiP <= 32 * MAX_WS_CHUNKS && units32 < 256LL * small_tiles_below()) return 16;
+  return 32;
 }
-inline int plan_grid(int N, int H, int W, int CoP, int max_wgs = 256) {
-  const int th = tile_rows(H), co_blocks = CoP / 64, units = N * ((H + th - 1) / th) * ((W + TW - 1) / TW);
+// Launch plan: persistent workgroups, a multiple of the channel-block count, at most one per tile and channel block.
+inline int plan_grid(int N, int H, int W, int CoP, int th, int max_wgs = 256) {
+  const int co_blocks = CoP / 64, units = N * ((H + th - 1) / th) * ((W + TW - 1) / TW);
   int per_block = max_wgs / co_blocks;
   if (per_block < 1) per_block = 1;
   if (per_block > units) per_block = units;
   return per_block * co_blocks;
 }
 // Rows of partial sums the kernel writes (in all, not per image): four per workgroup of a channel block.
-inline int stat_rows(int N, int H, int W, int CoP, int max_wgs = 256) { return 4 * (plan_grid(N, H, W, CoP, max_wgs) / (CoP / 64)); }
+inline int stat_rows(int N, int H, int W, int CoP, int th, int max_wgs = 256) {
+  return 4 * (plan_grid(N, H, W, CoP, th, max_wgs) / (CoP / 64));
+}
 
 // Whether the pipelined kernel serves this call.  It needs images of 16 rows and more, 64-channel output
 // blocks, and enough (tile, channel block) units to give every CU a workgroup: below that (single images at
@@ -477,7 +495,7 @@ inline int &min_rows() {  // laboratory switch: 32 keeps the 16-row variant off
 }
 inline bool eligible(int N, int H, int W, int CiP, int CoP) {
   if (!(H >= min_rows() && H >= 16 && W >= 16 && CoP % 64 == 0 && CiP % 32 == 0)) return false;
-  const int th = tile_rows(H);
+  const int th = tile_rows(N, H, W, CiP, CoP);
   return (i64)N * ((H + th - 1) / th) * ((W + TW - 1) / TW) * (CoP / 64) >= min_units();
 }
 

@@ -524,7 +524,7 @@ int launch_pipe(const pipe::Args &a, int grid, hipStream_t s) {
 }
 template <int EPI>
 int launch_pipe_ws(const pipe::Args &a, int grid, hipStream_t s) {
-  if (pipe::tile_rows(a.H) == 16)
+  if (pipe::tile_rows(a.N, a.H, a.W, a.nk * 32, a.CoP) == 16)
     return a.nk <= pipe::MAX_WS_CHUNKS ? launch_pipe<true, EPI, 16>(a, grid, s) : launch_pipe<false, EPI, 16>(a, grid, s);
   return a.nk <= pipe::MAX_WS_CHUNKS ? launch_pipe<true, EPI, 32>(a, grid, s) : launch_pipe<false, EPI, 32>(a, grid, s);
 }
@@ -533,7 +533,7 @@ int launch_pipe_from(const ConvArgs &c, hipStream_t s) {
   a.in = c.in; a.wt = c.wt; a.bias = c.bias; a.out = c.out; a.stats = c.stats;
   a.N = c.N; a.H = c.Ho; a.W = c.Wo; a.nk = c.Ci / 32; a.CoP = c.CoP;
   a.in_ld = c.in_ld; a.out_ld = c.out_ld; a.in_c = c.in_c;
-  const int th = pipe::tile_rows(c.Ho);
+  const int th = pipe::tile_rows(c.N, c.Ho, c.Wo, c.Ci, c.CoP);
   a.tilesX = (c.Wo + pipe::TW - 1) / pipe::TW; a.tilesY = (c.Ho + th - 1) / th;
   a.units = c.N * a.tilesX * a.tilesY; a.co_blocks = c.CoP / 64; a.co_valid = c.co_valid;
   a.accumulate = c.accumulate;
@@ -554,7 +554,7 @@ int launch_pipe_from(const ConvArgs &c, hipStream_t s) {
     a.nt_store = lab_bytes >= 0 ? (lab_bytes > 0 && out_bytes >= lab_bytes) : (data_gradient && out_bytes >= dgrad_bytes);
   }
   a.bz = c.bz; a.bz_ld = c.bz_ld; a.bcf = c.bcf; a.bred_c0 = c.bred_c0; a.affine = c.affine;
-  const int grid = pipe::plan_grid(c.N, c.Ho, c.Wo, c.CoP);
+  const int grid = pipe::plan_grid(c.N, c.Ho, c.Wo, c.CoP, th);
   static const bool xcd_off = getenv("UNET_LAB_NO_XCD_ORDER") != nullptr;  // laboratory switch (same results either way)
   a.xcd_order = (!xcd_off && grid % (8 * a.co_blocks) == 0) ? 1 : 0;
   if (c.affine) return launch_pipe_ws<pipe::EPI_AFF>(a, grid, s);
@@ -836,7 +836,7 @@ int unet_conv3x3_pipeline_min_units(int min_units) {
 
 int unet_conv3x3_stat_rows(int N, int H, int W, int CiP, int CoP) {
   if (CiP < 32) CiP = 32;
-  if (pipe::eligible(N, H, W, CiP, CoP)) return pipe::stat_rows(N, H, W, CoP);
+  if (pipe::eligible(N, H, W, CiP, CoP)) return pipe::stat_rows(N, H, W, CoP, pipe::tile_rows(N, H, W, CiP, CoP));
   return N * unet_conv3x3_stat_tiles(H, W);
 }
 
