@@ -151,9 +151,11 @@ def _rccl_rank(port, q, sync_bn, break_comm=False, bf16_gradients=False):
         want_g, want_p = np.asarray(plain.get_gradients()), np.asarray(plain.get_parameters())
         net = _make_net(64 << 10)
         net.set_parameters(p0)
-        if break_comm:   # the library's communicator cannot be created: torch.distributed takes over
+        if break_comm == "preflight":   # some rank cannot load RCCL: found out before the collective set-up
+            dp.library_transport_ready = lambda *args, **kwargs: (False, "simulated: cannot open librccl.so.1")
+        elif break_comm:   # the library's communicator cannot be created: torch.distributed takes over
             def no_comm(*args, **kwargs):
-                raise RuntimeError("simulated: cannot open librccl.so.1")
+                raise RuntimeError("simulated: ncclCommInitRank failed")
             dp.init_comm = no_comm
         trainer = dp.DataParallel(net, dev, bucket_bytes=64 << 10, force_collectives=True, sync_bn=sync_bn,
                                   bf16_gradients=bf16_gradients)
@@ -203,10 +205,12 @@ def test_rccl_transport_one_rank():
     assert np.isfinite(got_p).all()
 
 
-def test_torch_distributed_takes_over_when_the_library_communicator_fails():
-    """unet_comm_init_rank failing (simulated) must not end a data-parallel run: DataParallel then reduces the
-    gradient buckets with torch.distributed on the device buffers; on one rank the step equals the plain one."""
-    want_g, got_g, want_p, got_p, nb = _run_one_rank(False, break_comm=True)
+@pytest.mark.parametrize("how", ["preflight", "init"])
+def test_torch_distributed_takes_over_when_the_library_communicator_fails(how):
+    """RCCL not loadable on some rank, or unet_comm_init_rank failing (both simulated), must not end a
+    data-parallel run: DataParallel then reduces the gradient buckets with torch.distributed on the device
+    buffers; on one rank the step equals the plain one."""
+    want_g, got_g, want_p, got_p, nb = _run_one_rank(False, break_comm=how)
     assert np.array_equal(want_g, got_g)
     assert np.isfinite(got_p).all()
 

@@ -74,6 +74,24 @@ def init_comm(capi, group=None, device=None):
     return comm
 
 
+def library_transport_ready(capi, group=None, device=None):
+    """Whether EVERY rank of `group` can load RCCL through the C ABI.  unet_comm_init_rank is a collective: a rank
+    that cannot open the library never joins it and the others would wait for ever, so the ranks agree first
+    (a MIN over torch.distributed).  Returns (ready, this rank's error message or None)."""
+    ok, why = 1, None
+    try:
+        probe = ctypes.create_string_buffer(capi.lib().unet_comm_unique_id_bytes())
+        capi.unet_comm_get_unique_id(probe)      # opens librccl.so.1 and asks it for an id (discarded)
+    except RuntimeError as e:
+        ok, why = 0, str(e)
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        on_device = dist.get_backend(group) == "nccl"
+        flag = torch.tensor([ok], dtype=torch.int32, device=device if on_device else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        ok = int(flag.item())
+    return bool(ok), why
+
+
 class DataParallel:
     """Wraps a created neural_net.NeuralNet for synchronous data-parallel training."""
 
@@ -100,15 +118,20 @@ class DataParallel:
         if self.native:
             if self.force:
                 os.environ["UNET_COMM_FORCE"] = "1"   # run the collectives even in a one-rank communicator
-            try:
-                self.comm = init_comm(capi, group, device)
-            except RuntimeError as e:
-                # the library's own communicator could not be set up (e.g. no librccl.so.1 on the loader path):
-                # torch.distributed's collectives on the same device buffers do the same reduction, without the
-                # overlap with backward.  Every rank sees the same failure, so every rank takes this path.
+            # The library's own communicator may not come up (e.g. no librccl.so.1 on the loader path):
+            # torch.distributed's collectives on the same device buffers then do the same reduction, without the
+            # overlap with backward.  The ranks agree on that before any of them enters the collective set-up.
+            ready, why = library_transport_ready(capi, group, device)
+            failure = None if ready else (why or "another rank cannot load RCCL")
+            if ready:
+                try:
+                    self.comm = init_comm(capi, group, device)
+                except RuntimeError as e:
+                    failure = str(e)
+            if failure is not None:
                 if self.sync_bn:
-                    raise
-                print(f"unet_amd.dp: {e}; reducing gradients through torch.distributed instead", flush=True)
+                    raise RuntimeError(failure)
+                print(f"unet_amd.dp: {failure}; reducing gradients through torch.distributed instead", flush=True)
                 self.native = False
                 self.torch_device_reduce = True
             else:
