@@ -29,7 +29,9 @@ __device__ __forceinline__ void fma4x4(float (&acc)[16], float v, const float *w
 // ((15*stride + k)^2 per channel) and the weight slice [ci][tap][co] in LDS.
 constexpr int F_COB = 16, F_CIB = 8;
 
-template <int K>  // compile-time kernel size, 0 = runtime
+// COB = output channels per workgroup: F_COB, or 1 for single-channel layers (the segmentation head), which
+// would otherwise spend fifteen of sixteen multiplies on zero padding.  Per channel the sums are the same.
+template <int K, int COB = F_COB>  // K: compile-time kernel size, 0 = runtime
 __global__ __launch_bounds__(256) void conv_fwd_f32_kernel(
     const float *__restrict__ Wt, const float *__restrict__ X, float *__restrict__ Y, int Ci, int Co,
     int Ho, int Wo, int Hi, int Wi, int pad, int stride, int k_rt, int tilesW) {
@@ -42,12 +44,12 @@ __global__ __launch_bounds__(256) void conv_fwd_f32_kernel(
   float *wts = smem + ((F_CIB * PH * PWp + 3) & ~3);                   // [CIB][kk][COB]
   const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
   const int th0 = (blockIdx.x / tilesW) * TILE, tw0 = (blockIdx.x % tilesW) * TILE;
-  const int co0 = blockIdx.y * F_COB;
+  const int co0 = blockIdx.y * COB;
   const i64 n = blockIdx.z;
   const int ih0 = th0 * stride - pad, iw0 = tw0 * stride - pad;
-  float acc[F_COB];
+  float acc[COB];
 #pragma unroll
-  for (int i = 0; i < F_COB; ++i) acc[i] = 0.f;
+  for (int i = 0; i < COB; ++i) acc[i] = 0.f;
 
   for (int ci0 = 0; ci0 < Ci; ci0 += F_CIB) {
     __syncthreads();
@@ -59,8 +61,8 @@ __global__ __launch_bounds__(256) void conv_fwd_f32_kernel(
         v = X[((n * Ci + ci0 + ci) * Hi + ih) * Wi + iw];
       patch[(ci * PH + ph) * PWp + pw] = v;
     }
-    for (int e = tid; e < F_CIB * kk * F_COB; e += 256) {
-      const int co = e % F_COB, r = e / F_COB, t = r % kk, ci = r / kk;
+    for (int e = tid; e < F_CIB * kk * COB; e += 256) {
+      const int co = e % COB, r = e / COB, t = r % kk, ci = r / kk;
       float v = 0.f;
       if (ci0 + ci < Ci && co0 + co < Co) v = Wt[((i64)(ci0 + ci) * Co + co0 + co) * kk + t];
       wts[e] = v;
@@ -69,16 +71,23 @@ __global__ __launch_bounds__(256) void conv_fwd_f32_kernel(
 #pragma unroll 1
     for (int ci = 0; ci < F_CIB; ++ci) {
       const float *prow = patch + (ci * PH + ty * stride) * PWp + tx * stride;
-      const float *wrow = wts + ci * kk * F_COB;
+      const float *wrow = wts + ci * kk * COB;
       for (int kh = 0; kh < k; ++kh)
-        for (int kw = 0; kw < k; ++kw) fma4x4(acc, prow[kh * PWp + kw], wrow + (kh * k + kw) * F_COB);
+        for (int kw = 0; kw < k; ++kw) {
+          if constexpr (COB == 16) {
+            fma4x4(acc, prow[kh * PWp + kw], wrow + (kh * k + kw) * COB);
+          } else {
+#pragma unroll
+            for (int c = 0; c < COB; ++c) acc[c] = fmaf(prow[kh * PWp + kw], wrow[(kh * k + kw) * COB + c], acc[c]);
+          }
+        }
     }
   }
   const int ho = th0 + ty, wo = tw0 + tx;
   if (ho < Ho && wo < Wo) {
     const float *bias = Wt + (i64)Ci * Co * kk;
 #pragma unroll
-    for (int co = 0; co < F_COB; ++co)
+    for (int co = 0; co < COB; ++co)
       if (co0 + co < Co) Y[((n * Co + co0 + co) * Ho + ho) * Wo + wo] = acc[co] + bias[co0 + co];
   }
 }
@@ -565,7 +574,10 @@ int unet_convolve_f32(const float *weights, const float *inputs, float *activati
   }
   const int tilesH = (Ho + TILE - 1) / TILE, tilesW = (Wo + TILE - 1) / TILE;
   dim3 grid((unsigned)(tilesH * tilesW), (unsigned)((Co + F_COB - 1) / F_COB), (unsigned)N);
-  if (k == 3)
+  if (k == 3 && Co == 1)  // grid.y = 1 either way; the LDS request covers the smaller weight slice
+    hipLaunchKernelGGL((conv_fwd_f32_kernel<3, 1>), grid, dim3(256), lds, as_stream(s), weights, inputs, activations,
+                       Ci, Co, Ho, Wo, Hi, Wi, pad, stride, k, tilesW);
+  else if (k == 3)
     hipLaunchKernelGGL(conv_fwd_f32_kernel<3>, grid, dim3(256), lds, as_stream(s), weights, inputs, activations,
                        Ci, Co, Ho, Wo, Hi, Wi, pad, stride, k, tilesW);
   else if (k == 1)
