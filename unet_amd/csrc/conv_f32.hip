@@ -136,22 +136,57 @@ __global__ __launch_bounds__(256) void conv3x3_fwd_mfma_f32_kernel(const float *
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[m][b][r] = 0.f;
 
+  // Staging plan of this thread, the same for every stage: which patch and weight elements it fetches (offsets
+  // relative to the stage's first input channel; -1 = outside the image / past C_out: zero) and where they go in
+  // LDS.  A stage's loads are all issued together, and one stage ahead: they are in flight while the matrix cores
+  // work on the stage before (a load -> store loop per element cost a memory round trip per element).
+  constexpr int NPE = M_CIB * PR * PC, NWE = M_CIB * COB * 9;
+  constexpr int NP = (NPE + 255) / 256, NW = (NWE + 255) / 256;
+  int poff[NP], woff[NW];
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    const int e = tid + 256 * i, ci = e / (PR * PC), r = e - ci * PR * PC, ph = r / PC, pw = r - ph * PC;
+    const int ih = th0 - pad + ph, iw = tw0 - pad + pw;  // pad 1: same size; pad 0: the unpadded convolution
+    poff[i] = (e < NPE && ih >= 0 && ih < Hi && iw >= 0 && iw < Wi) ? (ci * Hi + ih) * Wi + iw : -1;
+  }
+#pragma unroll
+  for (int i = 0; i < NW; ++i) {  // global order (ci, co, tap): contiguous runs of COB * 9 floats
+    const int e = tid + 256 * i, ci = e / (COB * 9), r = e - ci * COB * 9, co = r / 9;
+    woff[i] = (e < NWE && co0 + co < Co) ? ci * Co * 9 + r : -1;
+  }
+  float pv[NP], wv[NW];
+  auto load_stage = [&](int ci0) {
+    const float *xs = X + (n * Ci + ci0) * (i64)Hi * Wi;
+    const float *ws = Wt + ((i64)ci0 * Co + co0) * 9;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int ci = (tid + 256 * i) / (PR * PC);
+      pv[i] = (poff[i] >= 0 && ci0 + ci < ci_end) ? xs[poff[i]] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+      const int ci = (tid + 256 * i) / (COB * 9);
+      wv[i] = (woff[i] >= 0 && ci0 + ci < ci_end) ? ws[woff[i]] : 0.f;
+    }
+  };
+  auto store_stage = [&]() {
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int e = tid + 256 * i, ci = e / (PR * PC), r = e - ci * PR * PC, ph = r / PC, pw = r - ph * PC;
+      if (NPE % 256 == 0 || e < NPE) patch[ci][ph][pw] = pv[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+      const int e = tid + 256 * i, ci = e / (COB * 9), r = e - ci * COB * 9, co = r / 9, t = r - co * 9;
+      if (NWE % 256 == 0 || e < NWE) wts[ci][t][co] = wv[i];
+    }
+  };
+  load_stage(ci_begin);
   for (int ci0 = ci_begin; ci0 < ci_end; ci0 += M_CIB) {
+    __syncthreads();  // the previous stage's fragment reads are done
+    store_stage();
     __syncthreads();
-    for (int e = tid; e < M_CIB * PR * PC; e += 256) {
-      const int ci = e / (PR * PC), r = e - ci * PR * PC, ph = r / PC, pw = r - ph * PC;
-      const int ih = th0 - pad + ph, iw = tw0 - pad + pw;  // pad 1: same size; pad 0: the unpadded convolution
-      float v = 0.f;
-      if (ci0 + ci < ci_end && ih >= 0 && ih < Hi && iw >= 0 && iw < Wi) v = X[((n * Ci + ci0 + ci) * Hi + ih) * Wi + iw];
-      patch[ci][ph][pw] = v;
-    }
-    for (int e = tid; e < M_CIB * COB * 9; e += 256) {  // global order (ci, co, tap): contiguous runs of COB * 9 floats
-      const int ci = e / (COB * 9), r = e - ci * COB * 9, co = r / 9, t = r - co * 9;
-      float v = 0.f;
-      if (ci0 + ci < ci_end && co0 + co < Co) v = Wt[((i64)(ci0 + ci) * Co + co0) * 9 + r];
-      wts[ci][t][co] = v;
-    }
-    __syncthreads();
+    if (ci0 + M_CIB < ci_end) load_stage(ci0 + M_CIB);
 #pragma unroll
     for (int pair = 0; pair < M_CIB / 2; ++pair) {
       const int ci = 2 * pair + kl;
