@@ -161,6 +161,12 @@ int unet_batch_norm_train_noalloc_max_partials(void);
 int unet_batch_norm_inference_f32(const float *inputs, float *activations, const float *weights,
                                   const float *BN_stats, int H, int W, int num_channels,
                                   int batch_size, unet_stream_t stream);
+/* unet_batch_norm_inference_f32 followed by unet_relu_f32 in one pass over the tensor (the reference runs
+ * cudaBatchNormInference and cudaRelu one after the other, convolution_layer_functions.h:59-71): the same
+ * values bit for bit, one read and one write less per element. */
+int unet_batch_norm_inference_relu_f32(const float *inputs, float *activations, const float *weights,
+                                       const float *BN_stats, int H, int W, int num_channels,
+                                       int batch_size, unet_stream_t stream);
 /* Replaces cudaBatchNormBackward: grad_weights[2c] = sum dy*xhat,
  * grad_weights[2c+1] = sum dy; dx = gamma/sqrt(var+eps)*(dy - (dbeta +
  * xhat*dgamma)/M). */

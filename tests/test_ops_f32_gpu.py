@@ -137,6 +137,26 @@ def test_batch_norm_golden(G, capi, golden, name):
     assert_close(yi, golden[name + "_yinf"], what=name + " inference")
 
 
+@pytest.mark.parametrize("shape", [(4, 64, 32, 32), (3, 5, 17, 9), (1, 1, 1, 1)])
+def test_batch_norm_inference_with_relu_equals_the_two_passes(G, capi, shape):
+    """unet_batch_norm_inference_relu_f32 = unet_batch_norm_inference_f32 then unet_relu_f32, bit for bit."""
+    n, c, h, w = shape
+    rng = np.random.default_rng(c)
+    x = G.dev((rng.standard_normal(shape) * 1.5 + 0.2).astype(np.float32))
+    gb = G.dev(rng.standard_normal(2 * c).astype(np.float32))
+    run = np.empty(2 * c, np.float32)
+    run[0::2], run[1::2] = rng.standard_normal(c), rng.random(c) + 0.1
+    run = G.dev(run)
+    y, two, one = G.empty(shape), G.empty(shape), G.empty(shape)
+    capi.unet_batch_norm_inference_f32(G.p(x), G.p(y), G.p(gb), G.p(run), h, w, c, n, None)
+    capi.unet_relu_f32(G.p(y), G.p(two), n * c * h * w, None)
+    capi.unet_batch_norm_inference_relu_f32(G.p(x), G.p(one), G.p(gb), G.p(run), h, w, c, n, None)
+    got, want = G.host(one), G.host(two)
+    np.testing.assert_array_equal(got, want)
+    assert (want == 0).any() or n * c * h * w == 1
+    assert (want > 0).any() or n * c * h * w == 1
+
+
 @pytest.mark.parametrize("shape", [(16, 64, 64, 64), (3, 5, 17, 9), (1, 1, 1, 1), (2, 130, 8, 8)])
 def test_batch_norm_vs_oracle(G, capi, oracle, shape):
     n, c, h, w = shape

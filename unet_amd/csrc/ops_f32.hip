@@ -359,6 +359,7 @@ __global__ __launch_bounds__(64) void bn_publish_kernel(const double *__restrict
 // MODE 0: train normalise (eps outside sqrt, stats = raw sums)
 // MODE 1: inference (eps inside sqrt, stats = [mean,var])
 // MODE 2: backward dx (stats = raw sums, gw = [dgamma,dbeta])
+// MODE 3: MODE 1 followed by ReLU (the same two roundings as the two passes, one pass over the tensor)
 template <int MODE>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float *__restrict__ x,
                                                        const float *__restrict__ dy,
@@ -372,7 +373,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float *__restrict__
     const int c = (int)(p % C);
     float a, b;  // out = a*x + b  (MODE 2: see below)
     float mean, inv, k1 = 0.f, k2 = 0.f;
-    if (MODE == 1) {
+    if (MODE == 1 || MODE == 3) {
       mean = stats[2 * c];
       inv = 1.0f / sqrtf(stats[2 * c + 1] + BN_EPS);
     } else {
@@ -399,7 +400,8 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float *__restrict__
         const float xh = (xp[i] - mean) * inv;
         op[i] = a * (gp[i] - k1 - xh * k2);
       } else {
-        op[i] = MODE == 0 ? gamma * ((xp[i] - mean) * inv) + gb[2 * c + 1] : a * xp[i] + b;
+        const float y = MODE == 0 ? gamma * ((xp[i] - mean) * inv) + gb[2 * c + 1] : a * xp[i] + b;
+        op[i] = (MODE == 3) ? (y > 0.f ? y : 0.f) : y;
       }
     }
   }
@@ -897,6 +899,19 @@ int unet_batch_norm_inference_f32(const float *inputs, float *activations, const
                      (const float *)nullptr, activations, weights, BN_stats, (const float *)nullptr, C, HW,
                      (i64)N * C, 1.0f);
   UNET_LAUNCH_CHECK("bn_apply_kernel<1>");
+  return UNET_OK;
+}
+
+int unet_batch_norm_inference_relu_f32(const float *inputs, float *activations, const float *weights,
+                                       const float *BN_stats, int H, int W, int C, int N, unet_stream_t s) {
+  int rc = bn_check("unet_batch_norm_inference_relu_f32", C, H, W, N);
+  if (rc) return rc;
+  UNET_REQUIRE(inputs && activations && weights && BN_stats, "unet_batch_norm_inference_relu_f32: NULL pointer");
+  const i64 HW = (i64)H * W;
+  hipLaunchKernelGGL(bn_apply_kernel<3>, bn_apply_grid(HW, (i64)N * C), dim3(256), 0, as_stream(s), inputs,
+                     (const float *)nullptr, activations, weights, BN_stats, (const float *)nullptr, C, HW,
+                     (i64)N * C, 1.0f);
+  UNET_LAUNCH_CHECK("bn_apply_kernel<3>");
   return UNET_OK;
 }
 

@@ -882,6 +882,11 @@ class Net {
                                       n.in_h, n.in_w, n.padding, n.stride, stream_));
         else
           UNET_CALL(unet_upsample_f32(in, w, n.z.f32(), n.kernel, n.in_c, n.out_c, n.in_h, n.in_w, batch, stream_));
+        if (inference && effective_activation(n) == ReLU) {  // one pass instead of two; the same values
+          UNET_CALL(unet_batch_norm_inference_relu_f32(n.z.f32(), n.act.f32(), gb, n.running.f32(), n.out_h, n.out_w,
+                                                       n.out_c, batch, stream_));
+          break;
+        }
         if (inference)
           UNET_CALL(unet_batch_norm_inference_f32(n.z.f32(), n.bn.f32(), gb, n.running.f32(), n.out_h, n.out_w,
                                                   n.out_c, batch, stream_));
