@@ -542,6 +542,79 @@ constexpr size_t kMaxDynLds = 64 * 1024;
 
 }  // namespace
 
+// ---- launch plan of the matrix-core 3x3 kernel (forward, and the data gradient as a forward pass over
+// flipped, transposed weights) ----
+struct MfmaConvPlan {
+  bool wide, two;
+  int tW, tH, cob, splits, ci_per_split;
+  i64 total;  // output elements
+};
+inline bool mfma_conv_serves(int k, int pad, int stride, int Co, int Ho, int Wo) {
+  return k == 3 && pad <= 1 && stride == 1 && Co >= 16 && Wo >= 8 && Ho >= 4;
+}
+inline MfmaConvPlan plan_mfma_conv(int N, int Ci, int Co, int Ho, int Wo) {
+  MfmaConvPlan p;
+  // 8 x 32 pixel tiles for wide images, 16 x 16 otherwise; 64 output channels per workgroup, 32 when that is
+  // needed to give every CU a workgroup
+  p.wide = Wo >= 32;
+  p.tW = p.wide ? (Wo + 31) / 32 : (Wo + 15) / 16;
+  p.tH = p.wide ? (Ho + 7) / 8 : (Ho + 15) / 16;
+  p.two = Co > 32 && (i64)p.tW * p.tH * N * ((Co + 63) / 64) >= 256;
+  p.cob = p.two ? (Co + 63) / 64 : (Co + 31) / 32;
+  // few workgroups (single images, deep levels): the input channels are split over more workgroups, each
+  // writing partial sums that a second kernel adds in a fixed order
+  int splits = 1;
+  const i64 wgs = (i64)p.tW * p.tH * N * p.cob;
+  if (wgs < 192) {
+    splits = (int)((384 + wgs - 1) / wgs);
+    const int max_splits = Ci / 32 > 0 ? Ci / 32 : 1;
+    if (splits > max_splits) splits = max_splits;
+    if (splits > 16) splits = 16;
+  }
+  p.ci_per_split = ((Ci + splits - 1) / splits + M_CIB - 1) / M_CIB * M_CIB;
+  p.splits = (Ci + p.ci_per_split - 1) / p.ci_per_split;
+  p.total = (i64)N * Co * Ho * Wo;
+  return p;
+}
+// `partial`: room for splits * total floats when the plan splits the input channels (else unused)
+int launch_mfma_conv(const MfmaConvPlan &p, const float *weights, const float *inputs, float *activations,
+                     float *partial, int N, int Ci, int Co, int Ho, int Wo, int Hi, int Wi, int pad, hipStream_t s) {
+  float *dst = p.splits > 1 ? partial : activations;
+  dim3 g((unsigned)(p.tW * p.tH), (unsigned)p.cob, (unsigned)(N * p.splits));
+  if (p.wide && p.two)
+    hipLaunchKernelGGL((conv3x3_fwd_mfma_f32_kernel<32, 2>), g, dim3(256), 0, s, weights, inputs, dst, Ci, Co, Ho, Wo, p.tW, p.splits, p.ci_per_split, Hi, Wi, pad);
+  else if (p.wide)
+    hipLaunchKernelGGL((conv3x3_fwd_mfma_f32_kernel<32, 1>), g, dim3(256), 0, s, weights, inputs, dst, Ci, Co, Ho, Wo, p.tW, p.splits, p.ci_per_split, Hi, Wi, pad);
+  else if (p.two)
+    hipLaunchKernelGGL((conv3x3_fwd_mfma_f32_kernel<16, 2>), g, dim3(256), 0, s, weights, inputs, dst, Ci, Co, Ho, Wo, p.tW, p.splits, p.ci_per_split, Hi, Wi, pad);
+  else
+    hipLaunchKernelGGL((conv3x3_fwd_mfma_f32_kernel<16, 1>), g, dim3(256), 0, s, weights, inputs, dst, Ci, Co, Ho, Wo, p.tW, p.splits, p.ci_per_split, Hi, Wi, pad);
+  UNET_LAUNCH_CHECK("conv3x3_fwd_mfma_f32_kernel");
+  if (p.splits > 1) {
+    hipLaunchKernelGGL(conv_split_reduce_f32_kernel, dim3(ew_grid(p.total)), dim3(256), 0, s, (const float *)dst,
+                       weights + (i64)Ci * Co * 9, activations, p.total, (i64)Ho * Wo, Co, p.splits);
+    UNET_LAUNCH_CHECK("conv_split_reduce_f32_kernel");
+  }
+  return UNET_OK;
+}
+
+// Weights of the data gradient as a forward pass: out[co][ci][tap] = w[ci][co][8 - tap] (channels transposed,
+// filter rotated by 180 degrees), followed by Ci zeros where the forward kernel looks for its bias.
+__global__ __launch_bounds__(256) void flip_weights_f32_kernel(const float *__restrict__ w, float *__restrict__ out,
+                                                               int Ci, int Co) {
+  const i64 nW = (i64)Ci * Co * 9;
+  for (i64 i = (i64)blockIdx.x * 256 + threadIdx.x; i < nW + Ci; i += (i64)gridDim.x * 256) {
+    float v = 0.f;
+    if (i < nW) {
+      const int t = (int)(i % 9);
+      const i64 r = i / 9;
+      const int ci = (int)(r % Ci), co = (int)(r / Ci);
+      v = w[((i64)ci * Co + co) * 9 + (8 - t)];
+    }
+    out[i] = v;
+  }
+}
+
 extern "C" {
 
 int unet_convolve_f32(const float *weights, const float *inputs, float *activations, int64_t act_len,
@@ -563,49 +636,16 @@ int unet_convolve_f32(const float *weights, const float *inputs, float *activati
                           stride, lds);
   const double flops = 2.0 * N * Co * Ho * Wo * (double)Ci * k * k;
   ProfScope prof(PROF_CONV_FWD_F32, flops, 4.0 * ((double)N * Ci * Hi * Wi + (double)N * Co * Ho * Wo), as_stream(s));
-  if (k == 3 && pad <= 1 && stride == 1 && Co >= 16 && Wo >= 8 && Ho >= 4) {
-    // matrix-core kernel: 8 x 32 pixel tiles for wide images, 16 x 16 otherwise; 64 output channels per
-    // workgroup, 32 when that is needed to give every CU a workgroup
-    const bool wide = Wo >= 32;
-    const int tW = wide ? (Wo + 31) / 32 : (Wo + 15) / 16, tH = wide ? (Ho + 7) / 8 : (Ho + 15) / 16;
-    const bool two = Co > 32 && (i64)tW * tH * N * ((Co + 63) / 64) >= 256;
-    const int cob = two ? (Co + 63) / 64 : (Co + 31) / 32;
-    // few workgroups (single images, deep levels): the input channels are split over more workgroups, each
-    // writing partial sums that a second kernel adds in a fixed order
-    int splits = 1;
-    const i64 wgs = (i64)tW * tH * N * cob;
-    if (wgs < 192) {
-      splits = (int)((384 + wgs - 1) / wgs);
-      const int max_splits = Ci / 32 > 0 ? Ci / 32 : 1;
-      if (splits > max_splits) splits = max_splits;
-      if (splits > 16) splits = 16;
-    }
-    int ci_per_split = ((Ci + splits - 1) / splits + M_CIB - 1) / M_CIB * M_CIB;
-    splits = (Ci + ci_per_split - 1) / ci_per_split;
-    float *dst = activations;
-    const i64 total = (i64)N * Co * Ho * Wo;
-    if (splits > 1) {
+  if (mfma_conv_serves(k, pad, stride, Co, Ho, Wo)) {
+    const MfmaConvPlan pl = plan_mfma_conv(N, Ci, Co, Ho, Wo);
+    float *partial = nullptr;
+    if (pl.splits > 1) {
       void *ws;
-      int rc = unet_workspace(&ws, sizeof(float) * (size_t)splits * (size_t)total, as_stream(s));
+      int rc = unet_workspace(&ws, sizeof(float) * (size_t)pl.splits * (size_t)pl.total, as_stream(s));
       if (rc) return rc;
-      dst = (float *)ws;
+      partial = (float *)ws;
     }
-    dim3 g((unsigned)(tW * tH), (unsigned)cob, (unsigned)(N * splits));
-    if (wide && two)
-      hipLaunchKernelGGL((conv3x3_fwd_mfma_f32_kernel<32, 2>), g, dim3(256), 0, as_stream(s), weights, inputs, dst, Ci, Co, Ho, Wo, tW, splits, ci_per_split, Hi, Wi, pad);
-    else if (wide)
-      hipLaunchKernelGGL((conv3x3_fwd_mfma_f32_kernel<32, 1>), g, dim3(256), 0, as_stream(s), weights, inputs, dst, Ci, Co, Ho, Wo, tW, splits, ci_per_split, Hi, Wi, pad);
-    else if (two)
-      hipLaunchKernelGGL((conv3x3_fwd_mfma_f32_kernel<16, 2>), g, dim3(256), 0, as_stream(s), weights, inputs, dst, Ci, Co, Ho, Wo, tW, splits, ci_per_split, Hi, Wi, pad);
-    else
-      hipLaunchKernelGGL((conv3x3_fwd_mfma_f32_kernel<16, 1>), g, dim3(256), 0, as_stream(s), weights, inputs, dst, Ci, Co, Ho, Wo, tW, splits, ci_per_split, Hi, Wi, pad);
-    UNET_LAUNCH_CHECK("conv3x3_fwd_mfma_f32_kernel");
-    if (splits > 1) {
-      hipLaunchKernelGGL(conv_split_reduce_f32_kernel, dim3(ew_grid(total)), dim3(256), 0, as_stream(s), (const float *)dst,
-                         weights + (i64)Ci * Co * 9, activations, total, (i64)Ho * Wo, Co, splits);
-      UNET_LAUNCH_CHECK("conv_split_reduce_f32_kernel");
-    }
-    return UNET_OK;
+    return launch_mfma_conv(pl, weights, inputs, activations, partial, N, Ci, Co, Ho, Wo, Hi, Wi, pad, as_stream(s));
   }
   const int tilesH = (Ho + TILE - 1) / TILE, tilesW = (Wo + TILE - 1) / TILE;
   dim3 grid((unsigned)(tilesH * tilesW), (unsigned)((Co + F_COB - 1) / F_COB), (unsigned)N);
@@ -639,7 +679,25 @@ int unet_convolve_backward_f32(const float *grad_activations, const float *input
     return unet_set_error(UNET_ERR_UNSUPPORTED, "unet_convolve_backward_f32: kernel size %d (supported: 1,3,5,7)", k);
 
   // ---- data gradient
-  if (grad_inputs) {
+  // 3x3 / stride 1 / pad 1: the forward matrix-core kernel on the gradient, with flipped and transposed weights
+  // (built per call: 36 bytes per weight against 36 bytes per weight and OUTPUT PIXEL of the convolution itself)
+  if (grad_inputs && pad == 1 && mfma_conv_serves(k, pad, stride, Ci, Hi, Wi)) {
+    const MfmaConvPlan pl = plan_mfma_conv(N, Co, Ci, Hi, Wi);
+    const size_t head = (((size_t)Ci * Co * 9 + Ci) + 63) & ~(size_t)63;
+    void *ws;
+    int rc = unet_workspace(&ws, sizeof(float) * (head + (pl.splits > 1 ? (size_t)pl.splits * (size_t)pl.total : 0)),
+                            as_stream(s));
+    if (rc) return rc;
+    float *flipped = (float *)ws;
+    ProfScope prof(PROF_CONV_DGRAD_F32, 2.0 * N * Co * Ho * Wo * (double)Ci * k * k,
+                   4.0 * ((double)N * Ci * Hi * Wi + (double)N * Co * Ho * Wo), as_stream(s));
+    hipLaunchKernelGGL(flip_weights_f32_kernel, dim3(ew_grid((i64)Ci * Co * 9 + Ci)), dim3(256), 0, as_stream(s), weights,
+                       flipped, Ci, Co);
+    UNET_LAUNCH_CHECK("flip_weights_f32_kernel");
+    rc = launch_mfma_conv(pl, flipped, grad_activations, grad_inputs, flipped + head, N, Co, Ci, Hi, Wi, Ho, Wo, 1,
+                          as_stream(s));
+    if (rc) return rc;
+  } else if (grad_inputs) {
     const int PH = (TILE - 1 + k - 1) / stride + 2;
     const size_t lds = sizeof(float) * ((((size_t)D_COC * PH * (PH + 1) + 3) & ~(size_t)3) + (size_t)D_COC * k * k * D_CIB);
     if (lds > kMaxDynLds)
