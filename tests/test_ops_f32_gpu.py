@@ -47,6 +47,9 @@ def test_conv_golden(G, golden, name):
     # n, ci, co, h, w, k, pad, stride
     (2, 3, 64, 40, 40, 3, 1, 1),     # the reference test's channel counts, smaller image
     (1, 20, 18, 33, 17, 3, 1, 1),    # ragged tiles, channel counts off the block sizes
+    (2, 64, 64, 40, 40, 3, 1, 1),    # matrix-core kernels forward and backward: 32-wide tiles, ragged at the border
+    (1, 130, 70, 16, 16, 3, 1, 1),   # several channel blocks, 16-wide tiles, the data gradient split over input channels
+    (3, 32, 48, 64, 33, 3, 1, 1),    # odd width, many 64-pixel regions per workgroup
     (2, 5, 7, 21, 30, 3, 1, 2),
     (1, 4, 6, 19, 19, 5, 2, 1),
     (1, 3, 4, 15, 18, 7, 3, 1),

@@ -362,6 +362,125 @@ __global__ __launch_bounds__(256) void conv_bwd_weight_f32_kernel(
   }
 }
 
+// ------------------------------------------- backward weights on the matrix cores --
+// 3x3 / stride 1 / pad 1:  dW[ci][co][tap] = sum over pixels of dY[co][pixel] * X[ci][pixel + off(tap)] as nine
+// GEMMs D[co][ci] += A[co][pixel] * B[pixel][ci] on v_mfma_f32_32x32x2_f32 (fp32 products and sums, like the
+// vector kernel).  A workgroup (4 waves) owns 64 output channels x 64 input channels -- one 32 x 32 block per
+// wave, nine taps = 144 accumulator registers -- and walks its share of 64-pixel regions (TW = 32: 2 rows x 32
+// columns; TW = 16: 4 rows x 16): the region's dY [64][64] and the halo patch of X [64][rows + 2][TW + 2] go
+// through LDS, the next region's loads in flight while the matrix cores work on this one.  The two K indices of
+// an MFMA are pixel j of the region's first and second half (lane half = region half), so a lane's operands of
+// four consecutive steps are consecutive floats: one 16-byte LDS read of dY per four steps, and per filter row two
+// 16-byte reads of X whose eight floats hold the sliding windows of all three filter columns.
+// Regions are split over gridDim.x workgroups; partial[split] is added up by reduce_partials_kernel in a fixed
+// order.  db[co] = sum dY comes from the staged dY tile (workgroups of the first input-channel block).
+template <int TW>
+__global__ __launch_bounds__(256, 1) void conv3x3_wgrad_mfma_f32_kernel(const float *__restrict__ dY,
+                                                                        const float *__restrict__ X,
+                                                                        float *__restrict__ partial, int N, int Ci,
+                                                                        int Co, int H, int W, int regions_per_split,
+                                                                        i64 nW) {
+  constexpr int TR = 64 / TW, PR = TR + 2, PCU = TW + 2;  // region rows, patch rows, patch columns in use
+  constexpr int PCP = TW + 8;                             // patch row pitch: window reads reach column TW + 3
+  constexpr int CIP = PR * PCP + 4;                       // floats per input channel (164 / 148: = 4, 20 mod 32)
+  constexpr int DYP = 68;                                 // floats per output channel of the dY tile
+  constexpr int NXE = 64 * PR * PCU, NX = (NXE + 255) / 256;
+  __shared__ __attribute__((aligned(16))) float dys[64 * DYP];
+  __shared__ __attribute__((aligned(16))) float xs[64 * CIP];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kl = lane >> 5, l32 = lane & 31;
+  const int mo = wave >> 1, no = wave & 1;
+  const int split = blockIdx.x, co0 = blockIdx.y * 64, ci0 = blockIdx.z * 64;
+  const int tilesX = (W + TW - 1) / TW, tilesY = (H + TR - 1) / TR;
+  const int regions = N * tilesY * tilesX;
+  const int r_begin = split * regions_per_split, r_end = min(regions, r_begin + regions_per_split);
+
+  f32x16_t acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  float bsum = 0.f;
+
+  float dv[16], xv[NX];
+  auto load_region = [&](int r) {
+    const int tx = r % tilesX, q = r / tilesX, ty = q % tilesY;
+    const i64 n = q / tilesY;
+    const int y0 = ty * TR, x0 = tx * TW;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int e = tid + 256 * i, co = e >> 6, px = e & 63, y = y0 + px / TW, x = x0 + px % TW;
+      dv[i] = (co0 + co < Co && y < H && x < W) ? dY[((n * Co + co0 + co) * H + y) * W + x] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      const int e = tid + 256 * i, ci = e / (PR * PCU), rr = e - ci * (PR * PCU), prow = rr / PCU, pcol = rr - prow * PCU;
+      const int iy = y0 - 1 + prow, ix = x0 - 1 + pcol;
+      xv[i] = (e < NXE && ci0 + ci < Ci && iy >= 0 && iy < H && ix >= 0 && ix < W)
+                  ? X[((n * Ci + ci0 + ci) * H + iy) * W + ix]
+                  : 0.f;
+    }
+  };
+  auto store_region = [&]() {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int e = tid + 256 * i;
+      dys[(e >> 6) * DYP + (e & 63)] = dv[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+      const int e = tid + 256 * i, ci = e / (PR * PCU), rr = e - ci * (PR * PCU), prow = rr / PCU, pcol = rr - prow * PCU;
+      if (NXE % 256 == 0 || e < NXE) xs[ci * CIP + prow * PCP + pcol] = xv[i];
+    }
+  };
+
+  const float *a_lane = dys + (32 * mo + l32) * DYP + kl * 32;
+  const float *b_lane = xs + (32 * no + l32) * CIP;
+  if (r_begin < r_end) load_region(r_begin);
+  for (int r = r_begin; r < r_end; ++r) {
+    __syncthreads();  // the previous region's fragment reads are done
+    store_region();
+    __syncthreads();
+    if (r + 1 < r_end) load_region(r + 1);
+    if (blockIdx.z == 0 && tid < 64) {  // bias gradient: this channel's 64 staged values, in order
+      const float4 *row = reinterpret_cast<const float4 *>(dys + tid * DYP);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const float4 v = row[i];
+        bsum += v.x; bsum += v.y; bsum += v.z; bsum += v.w;
+      }
+    }
+#pragma unroll
+    for (int jq = 0; jq < 8; ++jq) {  // four MFMA steps per trip: region pixels 4 jq .. 4 jq + 3 of this lane's half
+      const float4 a4 = *reinterpret_cast<const float4 *>(a_lane + jq * 4);
+      const float a[4] = {a4.x, a4.y, a4.z, a4.w};
+      const int prow0 = TW == 32 ? kl : 2 * kl + (jq >> 2), col0 = TW == 32 ? jq * 4 : (jq & 3) * 4;
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh) {
+        const float4 *wp = reinterpret_cast<const float4 *>(b_lane + (prow0 + kh) * PCP + col0);
+        const float4 w0 = wp[0], w1 = wp[1];
+        const float win[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};  // patch columns col0 .. col0 + 7
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+          for (int st = 0; st < 4; ++st)
+            acc[kh * 3 + kw] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[st], win[st + kw], acc[kh * 3 + kw], 0, 0, 0);
+      }
+    }
+  }
+  float *out = partial + (i64)split * (nW + Co);
+  const int ci = ci0 + 32 * no + l32;
+  if (ci < Ci) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {  // register r holds row (r & 3) + 8 (r >> 2) + 4 (lane >> 5) of column lane % 32
+        const int co = co0 + 32 * mo + (r & 3) + 8 * (r >> 2) + 4 * kl;
+        if (co < Co) out[((i64)ci * Co + co) * 9 + t] = acc[t][r];
+      }
+  }
+  if (blockIdx.z == 0 && tid < 64 && co0 + tid < Co) out[nW + co0 + tid] = bsum;
+}
+
 // out[i] = sum_s partial[s*stride_s + i], i < n  (double accumulation)
 __global__ __launch_bounds__(256) void reduce_partials_kernel(const float *__restrict__ partial,
                                                               float *__restrict__ out, i64 n, int splits) {
@@ -713,6 +832,36 @@ int unet_convolve_backward_f32(const float *grad_activations, const float *input
 
   // ---- weight and bias gradient
   const i64 nW = (i64)Ci * Co * k * k;
+  if (k == 3 && stride == 1 && pad == 1 && Ci >= 16 && Co >= 16 && Wo >= 8 && Ho >= 4) {
+    // matrix-core kernel: 64 x 64 channel blocks, the 64-pixel regions split over enough workgroups to fill the device
+    const bool wide = Wo >= 32;
+    const int tw = wide ? 32 : 16, tr = 64 / tw;
+    const i64 regions = (i64)N * ((Ho + tr - 1) / tr) * ((Wo + tw - 1) / tw);
+    UNET_REQUIRE(regions < (1ll << 30), "unet_convolve_backward_f32: too many pixels for one call");
+    const int blocks = ((Co + 63) / 64) * ((Ci + 63) / 64);
+    i64 splits = (256 + blocks - 1) / blocks;
+    if (splits > regions) splits = regions;
+    if (splits > 512) splits = 512;
+    const int rps = (int)((regions + splits - 1) / splits);
+    splits = (regions + rps - 1) / rps;
+    void *ws;
+    int rc = unet_workspace(&ws, sizeof(float) * (size_t)splits * (size_t)(nW + Co), as_stream(s));
+    if (rc) return rc;
+    dim3 grid((unsigned)splits, (unsigned)((Co + 63) / 64), (unsigned)((Ci + 63) / 64));
+    ProfScope prof(PROF_CONV_WGRAD_F32, 2.0 * N * Co * Ho * Wo * (double)Ci * k * k,
+                   4.0 * ((double)N * Ci * Hi * Wi + (double)N * Co * Ho * Wo), as_stream(s));
+    if (wide)
+      hipLaunchKernelGGL(conv3x3_wgrad_mfma_f32_kernel<32>, grid, dim3(256), 0, as_stream(s), grad_activations, inputs,
+                         (float *)ws, N, Ci, Co, Ho, Wo, rps, nW);
+    else
+      hipLaunchKernelGGL(conv3x3_wgrad_mfma_f32_kernel<16>, grid, dim3(256), 0, as_stream(s), grad_activations, inputs,
+                         (float *)ws, N, Ci, Co, Ho, Wo, rps, nW);
+    UNET_LAUNCH_CHECK("conv3x3_wgrad_mfma_f32_kernel");
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(ew_grid(nW + Co)), dim3(256), 0, as_stream(s), (const float *)ws,
+                       grad_weights, nW + Co, (int)splits);
+    UNET_LAUNCH_CHECK("reduce_partials_kernel");
+    return UNET_OK;
+  }
   const int COB = k == 1 ? 16 : k == 3 ? 8 : k == 5 ? 2 : 1;
   const int cogroups = (Co + COB - 1) / COB;
   const int rows = N * Ho;
