@@ -648,6 +648,111 @@ __global__ __launch_bounds__(256) void upsample_bwd_weight_f32_kernel(
   }
 }
 
+// The same on the matrix cores for scale 2: four GEMMs D_t[co][ci] += dY[co][2y + i][2x + j] * X[ci][y][x], t = 2i + j,
+// on v_mfma_f32_32x32x2_f32.  A workgroup owns 64 x 64 channels (a 32 x 32 block and four phases = 64 accumulator
+// registers per wave) and walks 32-pixel regions of the input grid (TW = 32: one row x 32 columns; TW = 16: two
+// rows x 16): X [64][32] and the matching raw piece of dY [64][2 TR][2 TW] go through LDS one region ahead.  Lane
+// half = region half, so four steps of a lane are four consecutive input pixels: one 16-byte read of X, and per
+// output row two 16-byte reads of dY whose eight floats interleave the two column phases.
+template <int TW>
+__global__ __launch_bounds__(256) void upsample2_wgrad_mfma_f32_kernel(const float *__restrict__ dY,
+                                                                       const float *__restrict__ X,
+                                                                       float *__restrict__ partial, int N, int Ci,
+                                                                       int Co, int Hi, int Wi, int regions_per_split,
+                                                                       i64 nW) {
+  constexpr int TR = 32 / TW, OR = 2 * TR, OC = 2 * TW;  // region rows; rows and columns of its piece of dY
+  constexpr int XP = 36, DP = OR * OC + 4;               // floats per channel in LDS (= 4 mod 32)
+  __shared__ __attribute__((aligned(16))) float xs[64 * XP];
+  __shared__ __attribute__((aligned(16))) float dyr[64 * DP];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kl = lane >> 5, l32 = lane & 31;
+  const int mo = wave >> 1, no = wave & 1;
+  const int split = blockIdx.x, co0 = blockIdx.y * 64, ci0 = blockIdx.z * 64;
+  const int Ho = 2 * Hi, Wo = 2 * Wi;
+  const int tilesX = (Wi + TW - 1) / TW, tilesY = (Hi + TR - 1) / TR;
+  const int regions = N * tilesY * tilesX;
+  const int r_begin = split * regions_per_split, r_end = min(regions, r_begin + regions_per_split);
+  f32x16_t acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+  float bsum = 0.f;
+  float xv[8], dv[32];
+  auto load_region = [&](int r) {
+    const int tx = r % tilesX, q = r / tilesX, ty = q % tilesY;
+    const i64 n = q / tilesY;
+    const int y0 = ty * TR, x0 = tx * TW;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int e = tid + 256 * i, ci = e >> 5, px = e & 31, y = y0 + px / TW, x = x0 + px % TW;
+      xv[i] = (ci0 + ci < Ci && y < Hi && x < Wi) ? X[((n * Ci + ci0 + ci) * Hi + y) * Wi + x] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+      const int e = tid + 256 * i, co = e / (OR * OC), rr = e - co * (OR * OC), oy = 2 * y0 + rr / OC, ox = 2 * x0 + rr % OC;
+      dv[i] = (co0 + co < Co && oy < Ho && ox < Wo) ? dY[((n * Co + co0 + co) * Ho + oy) * Wo + ox] : 0.f;
+    }
+  };
+  auto store_region = [&]() {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int e = tid + 256 * i;
+      xs[(e >> 5) * XP + (e & 31)] = xv[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+      const int e = tid + 256 * i, co = e / (OR * OC);
+      dyr[co * DP + (e - co * (OR * OC))] = dv[i];
+    }
+  };
+  const float *a_lane = dyr + (32 * mo + l32) * DP;
+  const float *b_lane = xs + (32 * no + l32) * XP + kl * 16;
+  if (r_begin < r_end) load_region(r_begin);
+  for (int r = r_begin; r < r_end; ++r) {
+    __syncthreads();  // the previous region's fragment reads are done
+    store_region();
+    __syncthreads();
+    if (r + 1 < r_end) load_region(r + 1);
+    if (blockIdx.z == 0 && tid < 64) {  // bias gradient: this channel's staged values, in order
+      const float4 *row = reinterpret_cast<const float4 *>(dyr + tid * DP);
+#pragma unroll
+      for (int i = 0; i < OR * OC / 4; ++i) {
+        const float4 v = row[i];
+        bsum += v.x; bsum += v.y; bsum += v.z; bsum += v.w;
+      }
+    }
+#pragma unroll
+    for (int jq = 0; jq < 4; ++jq) {  // input pixels 4 jq .. 4 jq + 3 of this lane's half of the region
+      const float4 b4 = *reinterpret_cast<const float4 *>(b_lane + jq * 4);
+      const float b[4] = {b4.x, b4.y, b4.z, b4.w};
+      const int row = TW == 32 ? 0 : kl, col = TW == 32 ? kl * 16 + jq * 4 : jq * 4;  // of the first of the four pixels
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const float4 *gp = reinterpret_cast<const float4 *>(a_lane + (2 * row + i) * OC + 2 * col);
+        const float4 g0 = gp[0], g1 = gp[1];
+        const float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};  // output columns 2 col .. 2 col + 7
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int st = 0; st < 4; ++st)
+            acc[i * 2 + j] = __builtin_amdgcn_mfma_f32_32x32x2f32(g[2 * st + j], b[st], acc[i * 2 + j], 0, 0, 0);
+      }
+    }
+  }
+  float *out = partial + (i64)split * (nW + Co);
+  const int ci = ci0 + 32 * no + l32;
+  if (ci < Ci) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + 32 * mo + (r & 3) + 8 * (r >> 2) + 4 * kl;
+        if (co < Co) out[((i64)ci * Co + co) * 4 + t] = acc[t][r];
+      }
+  }
+  if (blockIdx.z == 0 && tid < 64 && co0 + tid < Co) out[nW + co0 + tid] = bsum;
+}
+
 int pick_splits(i64 base_blocks, i64 rows, i64 pixels_per_row) {
   i64 s = (2048 + base_blocks - 1) / base_blocks;
   const i64 by_work = (rows * pixels_per_row + 4095) / 4096;
@@ -927,6 +1032,33 @@ int unet_upsample_backward_f32(const float *grad_activations, const float *input
     UNET_LAUNCH_CHECK("upsample_bwd_data_f32_kernel");
   }
   const i64 nW = (i64)Ci * Co * scale * scale;
+  if (scale == 2 && Ci >= 16 && Co >= 16 && Wi >= 8) {  // matrix-core kernel
+    const bool wide = Wi >= 32;
+    const int tw = wide ? 32 : 16, tr = 32 / tw;
+    const i64 regions = (i64)N * ((Hi + tr - 1) / tr) * ((Wi + tw - 1) / tw);
+    UNET_REQUIRE(regions < (1ll << 30), "unet_upsample_backward_f32: too many pixels for one call");
+    const int blocks = ((Co + 63) / 64) * ((Ci + 63) / 64);
+    i64 splits = (512 + blocks - 1) / blocks;
+    if (splits > regions) splits = regions;
+    if (splits > 512) splits = 512;
+    const int rps = (int)((regions + splits - 1) / splits);
+    splits = (regions + rps - 1) / rps;
+    void *ws;
+    int rc = unet_workspace(&ws, sizeof(float) * (size_t)splits * (size_t)(nW + Co), as_stream(s));
+    if (rc) return rc;
+    dim3 grid((unsigned)splits, (unsigned)((Co + 63) / 64), (unsigned)((Ci + 63) / 64));
+    if (wide)
+      hipLaunchKernelGGL(upsample2_wgrad_mfma_f32_kernel<32>, grid, dim3(256), 0, as_stream(s), grad_activations, inputs,
+                         (float *)ws, N, Ci, Co, Hi, Wi, rps, nW);
+    else
+      hipLaunchKernelGGL(upsample2_wgrad_mfma_f32_kernel<16>, grid, dim3(256), 0, as_stream(s), grad_activations, inputs,
+                         (float *)ws, N, Ci, Co, Hi, Wi, rps, nW);
+    UNET_LAUNCH_CHECK("upsample2_wgrad_mfma_f32_kernel");
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(ew_grid(nW + Co)), dim3(256), 0, as_stream(s), (const float *)ws,
+                       grad_weights, nW + Co, (int)splits);
+    UNET_LAUNCH_CHECK("reduce_partials_kernel");
+    return UNET_OK;
+  }
   const int COB = scale == 2 ? 8 : scale == 3 ? 4 : 2;
   const int cogroups = (Co + COB - 1) / COB;
   const int rows = N * Hi;
