@@ -781,7 +781,10 @@ static int bn_check(const char *name, int C, int H, int W, int N) {
   return UNET_OK;
 }
 static dim3 bn_apply_grid(i64 HW, i64 planes) {
-  unsigned gx = (unsigned)((HW + 255) / 256);
+  // up to 16 elements per thread: a workgroup first fetches its plane's coefficients (a chain of dependent loads),
+  // and with one element per thread that prologue was most of its life
+  static const int lab_ept = getenv("UNET_LAB_BN_APPLY_EPT") ? atoi(getenv("UNET_LAB_BN_APPLY_EPT")) : 16;
+  unsigned gx = (unsigned)((HW + 256 * (i64)lab_ept - 1) / (256 * (i64)lab_ept));
   if (gx > 64) gx = 64;
   unsigned gy = planes > 16384 ? 16384u : (unsigned)planes;
   return dim3(gx, gy);
