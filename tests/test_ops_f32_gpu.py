@@ -246,9 +246,10 @@ def test_upsample_golden(G, capi, golden, name):
 
 
 @pytest.mark.parametrize("cfg", [(4, 64, 32, 32, 32, 2), (1, 19, 9, 7, 5, 2), (2, 3, 5, 4, 4, 3), (1, 2, 2, 3, 2, 4),
-                                 # the matrix-core weight gradient: 16-wide regions, several channel blocks; ragged
+                                 # the matrix-core forward and weight gradient: 16-wide regions, several channel blocks; ragged
                                  # regions and channel counts; odd width with 32-wide regions
-                                 (2, 80, 144, 16, 16, 2), (1, 20, 17, 9, 11, 2), (3, 32, 16, 6, 45, 2)])
+                                 (2, 80, 144, 16, 16, 2), (1, 20, 17, 9, 11, 2), (3, 32, 16, 6, 45, 2),
+                                 (1, 256, 64, 8, 8, 2)])   # forward: input channels split over workgroups
 def test_upsample_vs_oracle(G, capi, oracle, cfg):
     n, ci, co, h, w, s = cfg
     rng = np.random.default_rng(ci * 100 + co)

@@ -547,6 +547,101 @@ __global__ __launch_bounds__(256) void upsample_fwd_f32_kernel(
   }
 }
 
+// Forward on the matrix cores for scale 2: per output phase t = 2i + j a GEMM
+//   Y[co][2y + i][2x + j] = b[co] + sum_ci W[ci][co][t] * X[ci][y][x]   on v_mfma_f32_32x32x2_f32
+// (A = weights, rows = output channels; B = input pixels; two input channels per MFMA).  A workgroup owns 64 output
+// channels x 64 input pixels (TW = 32: 2 rows x 32 columns; TW = 16: 4 rows x 16) and all four phases -- a wave one
+// 32 x 32 block, 64 accumulator registers -- with 32 input channels per stage through LDS, the next stage's loads
+// in flight.  The two column phases of an output row leave as one 8-byte store per lane.  splits > 1: the input
+// channels are divided over blockIdx.z = image * splits + split, partial sums go to Y[split][...] without the bias
+// and conv_split_reduce_f32_kernel adds them in a fixed order (launches of few workgroups: single images).
+constexpr int UM_CIB = 32;
+template <int TW>
+__global__ __launch_bounds__(256) void upsample2_fwd_mfma_f32_kernel(const float *__restrict__ X,
+                                                                     const float *__restrict__ Wt,
+                                                                     float *__restrict__ Y, int Ci, int Co, int Hi,
+                                                                     int Wi, int tilesX, int splits, int ci_per_split) {
+  constexpr int TR = 64 / TW;
+  constexpr int WP = 4 * 64 + 8;  // floats per input channel of the weight stage [ci][t][64 co] (+8: = 8 mod 32)
+  constexpr int XP = 64 + 8;      // floats per input channel of the pixel stage
+  __shared__ float ws[UM_CIB * WP];
+  __shared__ float xs[UM_CIB * XP];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kl = lane >> 5, l32 = lane & 31;
+  const int mo = wave >> 1, no = wave & 1;
+  const int y0 = (blockIdx.x / tilesX) * TR, x0 = (blockIdx.x % tilesX) * TW;
+  const int co0 = blockIdx.y * 64;
+  const int split = blockIdx.z % splits;
+  const i64 n = blockIdx.z / splits, n_out = (i64)split * (gridDim.z / splits) + n;
+  const int ci_begin = split * ci_per_split, ci_end = min(Ci, ci_begin + ci_per_split);
+  const int Ho = 2 * Hi, Wo = 2 * Wi;
+  f32x16_t acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  // staging plan: weights as float4 (the four phases of one (ci, co) are contiguous), pixels as floats
+  constexpr int NWV = UM_CIB * 64 / 256, NXV = UM_CIB * 64 / 256;  // 8 + 8 per thread
+  float4 wv[NWV];
+  float xv[NXV];
+  auto load_stage = [&](int ci0) {
+#pragma unroll
+    for (int i = 0; i < NWV; ++i) {
+      const int e = tid + 256 * i, ci = e >> 6, co = e & 63;
+      wv[i] = (ci0 + ci < ci_end && co0 + co < Co)
+                  ? *reinterpret_cast<const float4 *>(Wt + ((i64)(ci0 + ci) * Co + co0 + co) * 4)
+                  : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < NXV; ++i) {
+      const int e = tid + 256 * i, ci = e >> 6, px = e & 63, y = y0 + px / TW, x = x0 + px % TW;
+      xv[i] = (ci0 + ci < ci_end && y < Hi && x < Wi) ? X[((n * Ci + ci0 + ci) * Hi + y) * Wi + x] : 0.f;
+    }
+  };
+  auto store_stage = [&]() {
+#pragma unroll
+    for (int i = 0; i < NWV; ++i) {
+      const int e = tid + 256 * i, ci = e >> 6, co = e & 63;
+      float *w = ws + ci * WP + co;
+      w[0] = wv[i].x; w[64] = wv[i].y; w[128] = wv[i].z; w[192] = wv[i].w;
+    }
+#pragma unroll
+    for (int i = 0; i < NXV; ++i) {
+      const int e = tid + 256 * i;
+      xs[(e >> 6) * XP + (e & 63)] = xv[i];
+    }
+  };
+  const float *a_lane = ws + kl * WP + 32 * mo + l32;
+  const float *b_lane = xs + kl * XP + 32 * no + l32;
+  load_stage(ci_begin);
+  for (int ci0 = ci_begin; ci0 < ci_end; ci0 += UM_CIB) {
+    __syncthreads();  // the previous stage's fragment reads are done
+    store_stage();
+    __syncthreads();
+    if (ci0 + UM_CIB < ci_end) load_stage(ci0 + UM_CIB);
+#pragma unroll
+    for (int kp = 0; kp < UM_CIB / 2; ++kp) {  // input channels 2 kp (lanes 0-31) and 2 kp + 1 (lanes 32-63)
+      const float b = b_lane[2 * kp * XP];
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_lane[2 * kp * WP + t * 64], b, acc[t], 0, 0, 0);
+    }
+  }
+  const int px = 32 * no + l32, y = y0 + px / TW, x = x0 + px % TW;
+  if (y < Hi && x < Wi) {
+    const float *bias = Wt + (i64)Ci * Co * 4;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = co0 + 32 * mo + (r & 3) + 8 * (r >> 2) + 4 * kl;
+      if (co >= Co) continue;
+      const float bv = splits > 1 ? 0.f : bias[co];
+      float *o = Y + ((n_out * Co + co) * Ho + 2 * y) * Wo + 2 * x;
+      *reinterpret_cast<float2 *>(o) = make_float2(acc[0][r] + bv, acc[1][r] + bv);
+      *reinterpret_cast<float2 *>(o + Wo) = make_float2(acc[2][r] + bv, acc[3][r] + bv);
+    }
+  }
+}
+
 // dX[n,ci,hi,wi] = sum_co sum_{i,j<s} W[ci,co,i,j] * dY[n,co,hi*s+i,wi*s+j]
 constexpr int UD_CIB = 8, UD_COC = 8;
 
@@ -998,6 +1093,44 @@ int unet_upsample_f32(const float *inputs, const float *weights, float *activati
   UNET_REQUIRE(inputs && weights && activations, "unet_upsample_f32: NULL pointer");
   UNET_REQUIRE(N > 0 && Ci > 0 && Co > 0 && Hi > 0 && Wi > 0 && scale > 0, "unet_upsample_f32: need positive sizes");
   UNET_REQUIRE(N <= 65535, "unet_upsample_f32: batch above 65535");
+  // matrix-core kernel (it loads the four phases of a weight as 16 bytes and stores output pairs as 8)
+  if (scale == 2 && Ci >= 16 && Co >= 16 && Wi >= 8 && ((uintptr_t)weights & 15) == 0 && ((uintptr_t)activations & 7) == 0) {
+    const bool wide = Wi >= 32;
+    const int tw = wide ? 32 : 16, tr = 64 / tw;
+    const int tilesX = (Wi + tw - 1) / tw, tilesY = (Hi + tr - 1) / tr, cob = (Co + 63) / 64;
+    int splits = 1;
+    const i64 wgs = (i64)tilesX * tilesY * cob * N;
+    if (wgs < 192) {  // single images, deep levels: divide the input channels over more workgroups
+      splits = (int)((384 + wgs - 1) / wgs);
+      const int max_splits = Ci / 64 > 0 ? Ci / 64 : 1;
+      if (splits > max_splits) splits = max_splits;
+      if (splits > 16) splits = 16;
+    }
+    const int ci_per_split = ((Ci + splits - 1) / splits + UM_CIB - 1) / UM_CIB * UM_CIB;
+    splits = (Ci + ci_per_split - 1) / ci_per_split;
+    const i64 total = (i64)N * Co * Hi * 2 * Wi * 2;
+    float *dst = activations;
+    if (splits > 1) {
+      void *ws;
+      int rc = unet_workspace(&ws, sizeof(float) * (size_t)splits * (size_t)total, as_stream(s));
+      if (rc) return rc;
+      dst = (float *)ws;
+    }
+    dim3 grid((unsigned)(tilesX * tilesY), (unsigned)cob, (unsigned)(N * splits));
+    if (wide)
+      hipLaunchKernelGGL(upsample2_fwd_mfma_f32_kernel<32>, grid, dim3(256), 0, as_stream(s), inputs, weights, dst, Ci, Co,
+                         Hi, Wi, tilesX, splits, ci_per_split);
+    else
+      hipLaunchKernelGGL(upsample2_fwd_mfma_f32_kernel<16>, grid, dim3(256), 0, as_stream(s), inputs, weights, dst, Ci, Co,
+                         Hi, Wi, tilesX, splits, ci_per_split);
+    UNET_LAUNCH_CHECK("upsample2_fwd_mfma_f32_kernel");
+    if (splits > 1) {
+      hipLaunchKernelGGL(conv_split_reduce_f32_kernel, dim3(ew_grid(total)), dim3(256), 0, as_stream(s), (const float *)dst,
+                         weights + (i64)Ci * Co * 4, activations, total, (i64)Hi * 2 * Wi * 2, Co, splits);
+      UNET_LAUNCH_CHECK("conv_split_reduce_f32_kernel");
+    }
+    return UNET_OK;
+  }
   const size_t lds16 = sizeof(float) * (size_t)16 * scale * scale * U_COB, lds64 = 4 * lds16;
   if (lds16 > kMaxDynLds) return unet_set_error(UNET_ERR_UNSUPPORTED, "unet_upsample_f32: scale %d too large", scale);
   const i64 opix = (i64)Hi * scale * Wi * scale;
