@@ -249,7 +249,9 @@ def test_upsample_golden(G, capi, golden, name):
                                  # the matrix-core forward and weight gradient: 16-wide regions, several channel blocks; ragged
                                  # regions and channel counts; odd width with 32-wide regions
                                  (2, 80, 144, 16, 16, 2), (1, 20, 17, 9, 11, 2), (3, 32, 16, 6, 45, 2),
-                                 (1, 256, 64, 8, 8, 2)])   # forward: input channels split over workgroups
+                                 (1, 256, 64, 8, 8, 2),    # forward: input channels split over workgroups
+                                 # enough workgroups for the matrix-core data gradient: 32- and 16-wide tiles, ragged
+                                 (8, 64, 32, 32, 32, 2), (4, 70, 20, 30, 35, 2), (16, 130, 48, 16, 16, 2)])
 def test_upsample_vs_oracle(G, capi, oracle, cfg):
     n, ci, co, h, w, s = cfg
     rng = np.random.default_rng(ci * 100 + co)

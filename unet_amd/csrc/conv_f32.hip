@@ -688,6 +688,83 @@ __global__ __launch_bounds__(256) void upsample_bwd_data_f32_kernel(
       if (ci0 + ci < Ci) dX[((n * Ci + ci0 + ci) * Hi + hi) * Wi + wi] = acc[ci];
 }
 
+// The data gradient on the matrix cores for scale 2:
+//   dX[ci][y][x] = sum_co sum_{i,j} W[ci][co][2i + j] * dY[co][2y + i][2x + j]
+// as one GEMM over K = (co, i, j); the two K indices of an MFMA are the column phases j = 0, 1 of one (co, i), so
+// the B operands of a wave are 64 consecutive floats of a dY row.  A workgroup owns 64 input channels x 64 input
+// pixels (a wave one 32 x 32 block), 16 output channels per stage through LDS, the next stage's loads in flight.
+constexpr int UDM_COB = 16;
+template <int TW>
+__global__ __launch_bounds__(256) void upsample2_dgrad_mfma_f32_kernel(const float *__restrict__ dY,
+                                                                       const float *__restrict__ Wt,
+                                                                       float *__restrict__ dX, int Ci, int Co, int Hi,
+                                                                       int Wi, int tilesX) {
+  constexpr int TR = 64 / TW, OR = 2 * TR, OC = 2 * TW;
+  constexpr int WP = 4 * 64 + 8, DP = OR * OC + 8;  // floats per output channel of a stage (= 8 mod 32)
+  __shared__ float wl[UDM_COB * WP];   // [co][t][64 ci]
+  __shared__ float dl[UDM_COB * DP];   // [co][2 TR rows][2 TW columns] of dY
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, kl = lane >> 5, l32 = lane & 31;
+  const int mo = wave >> 1, no = wave & 1;
+  const int y0 = (blockIdx.x / tilesX) * TR, x0 = (blockIdx.x % tilesX) * TW;
+  const int ci0 = blockIdx.y * 64;
+  const i64 n = blockIdx.z;
+  const int Ho = 2 * Hi, Wo = 2 * Wi;
+  f32x16_t acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  float4 wv[4];
+  float dv[16];
+  auto load_stage = [&](int cob) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = tid + 256 * i, ci = e >> 4, co = e & 15;
+      wv[i] = (ci0 + ci < Ci && cob + co < Co) ? *reinterpret_cast<const float4 *>(Wt + ((i64)(ci0 + ci) * Co + cob + co) * 4)
+                                               : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int e = tid + 256 * i, co = e / (OR * OC), rr = e - co * (OR * OC), oy = 2 * y0 + rr / OC, ox = 2 * x0 + rr % OC;
+      dv[i] = (cob + co < Co && oy < Ho && ox < Wo) ? dY[((n * Co + cob + co) * Ho + oy) * Wo + ox] : 0.f;
+    }
+  };
+  auto store_stage = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = tid + 256 * i, ci = e >> 4, co = e & 15;
+      float *w = wl + co * WP + ci;
+      w[0] = wv[i].x; w[64] = wv[i].y; w[128] = wv[i].z; w[192] = wv[i].w;
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int e = tid + 256 * i, co = e / (OR * OC);
+      dl[co * DP + (e - co * (OR * OC))] = dv[i];
+    }
+  };
+  const int px = 32 * no + l32, row = px / TW, col = px % TW;
+  const float *a_lane = wl + kl * 64 + 32 * mo + l32;          // + co * WP + i * 128
+  const float *b_lane = dl + 2 * row * OC + 2 * col + kl;      // + co * DP + i * OC
+  load_stage(0);
+  for (int cob = 0; cob < Co; cob += UDM_COB) {
+    __syncthreads();  // the previous stage's fragment reads are done
+    store_stage();
+    __syncthreads();
+    if (cob + UDM_COB < Co) load_stage(cob + UDM_COB);
+#pragma unroll
+    for (int co = 0; co < UDM_COB; ++co)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_lane[co * WP + i * 128], b_lane[co * DP + i * OC], acc, 0, 0, 0);
+  }
+  const int y = y0 + row, x = x0 + col;
+  if (y < Hi && x < Wi) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int ci = ci0 + 32 * mo + (r & 3) + 8 * (r >> 2) + 4 * kl;
+      if (ci < Ci) dX[((n * Ci + ci) * Hi + y) * Wi + x] = acc[r];
+    }
+  }
+}
+
 // dW[ci,co,i,j] = sum_{n,hi,wi} dY[n,co,hi*s+i,wi*s+j] * X[n,ci,hi,wi]; db[co] = sum dY.
 template <int S, int COB>
 __global__ __launch_bounds__(256) void upsample_bwd_weight_f32_kernel(
@@ -1157,7 +1234,18 @@ int unet_upsample_backward_f32(const float *grad_activations, const float *input
   UNET_REQUIRE(N <= 65535 && Ci <= 65535, "unet_upsample_backward_f32: batch or C_in above 65535");
   if (scale < 2 || scale > 4)
     return unet_set_error(UNET_ERR_UNSUPPORTED, "unet_upsample_backward_f32: scale %d (supported: 2,3,4)", scale);
-  if (grad_inputs) {
+  const int tw_d = Wi >= 32 ? 32 : 16, tiles_d = ((Wi + tw_d - 1) / tw_d) * ((Hi + 64 / tw_d - 1) / (64 / tw_d));
+  if (grad_inputs && scale == 2 && Ci >= 16 && Co >= 16 && Wi >= 8 && ((uintptr_t)weights & 15) == 0 &&
+      (i64)tiles_d * ((Ci + 63) / 64) * N >= 128) {  // matrix-core kernel, when there are workgroups enough for the device
+    dim3 grid((unsigned)tiles_d, (unsigned)((Ci + 63) / 64), (unsigned)N);
+    if (tw_d == 32)
+      hipLaunchKernelGGL(upsample2_dgrad_mfma_f32_kernel<32>, grid, dim3(256), 0, as_stream(s), grad_activations, weights,
+                         grad_inputs, Ci, Co, Hi, Wi, (Wi + 31) / 32);
+    else
+      hipLaunchKernelGGL(upsample2_dgrad_mfma_f32_kernel<16>, grid, dim3(256), 0, as_stream(s), grad_activations, weights,
+                         grad_inputs, Ci, Co, Hi, Wi, (Wi + 15) / 16);
+    UNET_LAUNCH_CHECK("upsample2_dgrad_mfma_f32_kernel");
+  } else if (grad_inputs) {
     const size_t lds = sizeof(float) * (size_t)UD_COC * scale * scale * UD_CIB;
     dim3 grid(cdiv_u((i64)Hi * Wi, 256), (unsigned)((Ci + UD_CIB - 1) / UD_CIB), (unsigned)N);
     hipLaunchKernelGGL(upsample_bwd_data_f32_kernel, grid, dim3(256), lds, as_stream(s), grad_activations, weights,
