@@ -269,6 +269,32 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float *__restrict
   // (n, i) of element j advance with j: one 64-bit division per thread, not per element
   i64 j = j0 + threadIdx.x;
   i64 n = j / HW, i = j - n * HW;
+  // eight elements per trip: their loads are in flight together, the additions stay in element order
+  constexpr int U = 8;
+  for (; j + (U - 1) * (i64)blockDim.x < j1; j += U * (i64)blockDim.x) {
+    float v[U], g[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      while (i >= HW) {
+        i -= HW;
+        ++n;
+      }
+      const i64 idx = (n * C + c) * HW + i;
+      v[u] = x[idx];
+      g[u] = MODE == 1 ? dy[idx] : 0.f;
+      i += blockDim.x;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (MODE == 0) {
+        acc[0] += v[u];
+        acc[1] += v[u] * v[u];
+      } else {
+        acc[0] += g[u] * ((v[u] - mean) * inv);
+        acc[1] += g[u];
+      }
+    }
+  }
   for (; j < j1; j += blockDim.x, i += blockDim.x) {
     while (i >= HW) {
       i -= HW;
