@@ -4,8 +4,12 @@
     python bench.py --gpus N --steps K --warmup W
 
 A step = one forward + backward + Adam update over one batch of synthetic
-images on every rank (one process per GPU; for N > 1 launch with
-`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`).
+images on every rank, one process per GPU.  For N > 1 the ranks come either from
+a launcher (`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N
+...`, which sets WORLD_SIZE) or, when the script is started plainly, from the
+script itself: it starts that launcher as a child process, relays its output and
+exits with its status (and with an error if the line the ranks print does not say
+n_gpus = N).  `--dry-launch` shows the ranks that would run and touches no GPU.
 Inputs are resident in HBM before the timed region starts.  Rank 0 prints ONE
 JSON line: whole-job images/s, the roofline position of the dominant kernel
 family (timed live with HIP events on the launch stream) and, at N = 1, a CPU
@@ -129,9 +133,49 @@ def cpu_baseline_torch(graph, batch=1, steps=1):
     return (time.perf_counter() - t0) / steps, cores
 
 
+def launch_ranks(args):
+    """Started without a launcher but asked for several GPUs: run the same command line under
+    torch.distributed.run as a CHILD process (one rank per GPU, rendezvous on 127.0.0.1), relay what it
+    prints, and fail unless rank 0's line reports the requested number of GPUs."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, UNET_BENCH_SELF_LAUNCHED="1")
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    reported, dry_ranks = None, set()
+    for line in proc.stdout:
+        sys.stdout.write(line)
+        sys.stdout.flush()
+        text = line.strip()
+        if text.startswith("{"):
+            try:
+                rec = json.loads(text)
+            except ValueError:
+                continue
+            if "n_gpus" in rec:
+                reported = rec["n_gpus"]
+            if "dry_launch_rank" in rec:
+                dry_ranks.add(rec["dry_launch_rank"])
+    rc = proc.wait()
+    if rc == 0 and args.dry_launch and dry_ranks != set(range(args.gpus)):
+        print(f"bench.py: --gpus {args.gpus} but the ranks that started were {sorted(dry_ranks)}", file=sys.stderr)
+        rc = 1
+    if rc == 0 and not args.dry_launch and reported != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but the ranks reported n_gpus = {reported}", file=sys.stderr)
+        rc = 1
+    sys.exit(rc)
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=int(os.environ.get("UNET_NGPU", "1") or 1),
+                    help="GPUs of this node, one rank each (default: UNET_NGPU, else 1)")
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="start the ranks, have each print its RANK / WORLD_SIZE, touch no GPU")
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=16, help="images per GPU per step")
@@ -146,6 +190,19 @@ def main():
     ap.add_argument("--no-prof", action="store_true", help="skip the per-kernel event timing")
     args = ap.parse_args()
 
+    # Ranks first, before anything touches a GPU: a plain `python bench.py --gpus N` starts its own launcher.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(args)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.dry_launch:
+        print(json.dumps({"dry_launch_rank": int(os.environ.get("RANK", "0")),
+                          "world_size": int(os.environ.get("WORLD_SIZE", "1")),
+                          "local_rank": int(os.environ.get("LOCAL_RANK", "0")),
+                          "master": f"{os.environ.get('MASTER_ADDR', '-')}:{os.environ.get('MASTER_PORT', '-')}"}),
+              flush=True)
+        return
     if args.dtype:
         os.environ["UNET_DTYPE"] = args.dtype
     import torch
@@ -154,11 +211,8 @@ def main():
     import torch_ref
     from unet_amd import capi, dp
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     capi.unet_set_device(local_rank)
@@ -188,6 +242,17 @@ def main():
     trainer = dp.DataParallel(net, device)
     trainer.broadcast_parameters()
     lr = 1e-3
+    # What carries the gradient mean, as the communicator itself reports it (the line must show whether a
+    # multi-GPU figure came from the overlapped RCCL path of the C ABI or from a fallback).
+    rccl_ranks, transport = 0, "none (one rank)"
+    if trainer.comm is not None:
+        ws, rk = ctypes.c_int(), ctypes.c_int()
+        capi.unet_comm_size(trainer.comm, ctypes.byref(ws), ctypes.byref(rk))
+        rccl_ranks, transport = ws.value, "rccl-native"
+    elif trainer.torch_device_reduce:
+        transport = "torch-fallback"
+    elif world > 1:
+        transport = "host-staged"
 
     def one_step():
         if args.infer:
@@ -312,6 +377,8 @@ def main():
         "hbm_in_use_gb": round((free0 - free1) / 1e9, 2),
         "step_tflops": round((fwd_flops if args.infer else step_flops) * world / elapsed * args.steps / 1e12, 2),
         "final_loss": loss,
+        "rccl_ranks": rccl_ranks, "transport": transport,
+        "gradient_dtype_on_links": ("bf16" if os.environ.get("UNET_GRAD_BF16", "0") not in ("", "0") else "f32") if rccl_ranks else None,
     }
     if families:
         mfma_bound = {CONV3, WGRAD3, "conv_mfma_kernel<1,64>",
