@@ -186,9 +186,24 @@ int main(int argc, char **argv) {
         hipLaunchKernelGGL((pipe::conv3x3_pipe_kernel<false, pipe::EPI_PLAIN>), dim3(grid), dim3(512), pipe::LDS_BYTES, 0, c);
     };
     const float t_bred = time_launch(launch_bred, 20), t_plain = time_launch(launch_plain, 20);
+    // checksums of the fused-reduction variant's output and partial sums (compared between builds of this file)
+    CK(hipMemset(d_out, 0xff, out_n * 2));
+    CK(hipMemset(d_stats, 0xff, (size_t)rows * s.Co * 8));
+    launch_bred();
+    CK(hipDeviceSynchronize());
+    CK(hipMemcpy(h_out.data(), d_out, out_n * 2, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(sn.data(), d_stats, sn.size() * 4, hipMemcpyDeviceToHost));
+    uint64_t ck_out = 0, ck_stats = 0;
+    for (size_t i = 0; i < out_n; ++i) ck_out = ck_out * 1099511628211ull + h_out[i];
+    for (size_t i = 0; i < sn.size(); ++i) {
+      uint32_t u;
+      memcpy(&u, &sn[i], 4);
+      ck_stats = ck_stats * 1099511628211ull + u;
+    }
     printf("  [plain %6.1f us %5.0f TF | bred %6.1f us %5.0f TF] ", t_plain, flops / t_plain * 1e-6, t_bred, flops / t_bred * 1e-6);
-    printf("%4dx%-4d %4d->%-4d %s grid %4d | library %6.1f us %5.0f TF | pipe %6.1f us %5.0f TF | mismatches %zu, stats rel %.2e\n",
-           s.H, s.H, s.Ci, s.Co, ws ? "WS" : "  ", grid, t_lib, flops / t_lib * 1e-6, t_new, flops / t_new * 1e-6, bad, worst);
+    printf("%4dx%-4d %4d->%-4d %s grid %4d | library %6.1f us %5.0f TF | pipe %6.1f us %5.0f TF | mismatches %zu, stats rel %.2e | bred sums %016llx %016llx\n",
+           s.H, s.H, s.Ci, s.Co, ws ? "WS" : "  ", grid, t_lib, flops / t_lib * 1e-6, t_new, flops / t_new * 1e-6, bad, worst,
+           (unsigned long long)ck_out, (unsigned long long)ck_stats);
     fflush(stdout);
   }
   return 0;

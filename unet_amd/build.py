@@ -19,13 +19,23 @@ LIBDIR = os.path.join(ROOT, "unet_amd", "lib")
 OBJDIR = os.path.join(ROOT, "build", "obj")
 HIP_LIB = os.path.join(LIBDIR, "libunet_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-# -fno-slp-vectorize: the SLP vectoriser pairs independent fp32 operations into packed instructions
-# (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32).  On MI355X such arithmetic returned wrong results in waves that
-# shared a SIMD with waves of this library's MFMA kernels (csrc/bf16_util.h, keep_scalar); the scalar form never
-# did.  Without the pass the device code holds almost no packed fp32 arithmetic, and the training step takes the
-# same time (7.27 ms either way: these kernels are bound by HBM or by the matrix cores, not by VALU issue).
+# No packed fp32 arithmetic in device code.  On MI355X v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 returned wrong
+# results in waves that shared a SIMD with waves of this library's MFMA kernels (csrc/bf16_util.h, keep_scalar);
+# the scalar form never did.  Two switches:
+#   -target-feature -packed-fp32-ops   the device code is compiled for a gfx950 without that feature, so the
+#       backend has no such instruction to select, whatever forms <2 x float> operations (SLP vectoriser,
+#       ext_vector arithmetic in the sources, the legaliser).  It is a cc1 option and so reaches the host pass
+#       too, which answers "not a recognized feature for this target (ignoring feature)"; build_hip() drops
+#       those lines.  (A per-function target attribute does the same for the instructions but stops the inliner
+#       at every call into the HIP headers and the device library: thousands of real calls.)
+#   -fno-slp-vectorize                 kept: without the pass the scalar code is not first paired and then split.
+# tests/test_no_packed_fp32_cpu.py disassembles the built library and fails on any such instruction.  The
+# training step takes the same time either way (these kernels are bound by HBM or by the matrix cores, not by
+# VALU issue).
+NO_PACKED_FP32 = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize", "-Wall", "-Wno-unused-function",
-             "-Wno-unused-variable", "-Wno-unused-but-set-variable"]
+             "-Wno-unused-variable", "-Wno-unused-but-set-variable"] + NO_PACKED_FP32
+HOST_PASS_NOISE = "is not a recognized feature for this target (ignoring feature)"
 # Per-file extra flags.  wgrad_bf16: MFMA accumulators stay in ordinary vector registers (no copies
 # to and from the accumulation half of the register file around the loop-carried accumulators).
 EXTRA_FLAGS = {"wgrad_bf16.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
@@ -55,8 +65,15 @@ def build_hip(force=False, verbose=False):
             cmd = [HIPCC] + HIP_FLAGS + EXTRA_FLAGS.get(os.path.basename(src), []) + ["-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd))
-            procs.append((src, subprocess.Popen(cmd)))
-    failed = [src for src, p in procs if p.wait() != 0]
+            procs.append((src, subprocess.Popen(cmd, stderr=subprocess.PIPE, text=True)))
+    failed = []
+    for src, p in procs:
+        _, err = p.communicate()
+        err = "".join(l for l in err.splitlines(True) if HOST_PASS_NOISE not in l)
+        if err.strip():
+            sys.stderr.write(err)
+        if p.returncode != 0:
+            failed.append(src)
     if failed:
         raise RuntimeError("hipcc failed for: " + ", ".join(failed))
     if force or procs or _newer(HIP_LIB, objs):
