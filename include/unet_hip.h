@@ -330,12 +330,16 @@ int unet_difference_loss_backward_f32(const float *mask, const float *y, float *
 /* Softmax cross-entropy over the channel axis, mean over N*H*W pixels
  * (torch.nn.functional.cross_entropy semantics; the reference only names
  * SOFTMAX in an enum, layer.h:31).  logits [N,C,H,W], target int32 [N,H,W];
- * loss_out = device float (mean loss); dlogits may be NULL. */
+ * loss_out = device float (mean loss); dlogits may be NULL.  A target outside
+ * [0, num_classes) marks its pixel as ignored (an "ignore label" such as 255 or
+ * -1): no loss, zero gradient, and the mean is over the remaining pixels (0 if
+ * there are none). */
 int unet_softmax_xent_f32(const float *logits, const int32_t *target, float *dlogits,
                           float *loss_out, int batch_size, int num_classes, int H, int W,
                           unet_stream_t stream);
 /* Helpers of the engine's cross-entropy loss (no counterpart in the reference): class indices handed over as
- * floats -> int32 (rounded to nearest); out[n][pixel] = arg max over the C channels of x[n][:][pixel] (first
+ * floats -> int32 (rounded to nearest; NaN and values beyond the int32 range become -1, which
+ * unet_softmax_xent_f32 ignores); out[n][pixel] = arg max over the C channels of x[n][:][pixel] (first
  * on ties), as a float. */
 int unet_f32_to_i32(const float *in, int32_t *out, int64_t n, unet_stream_t stream);
 int unet_argmax_channels_f32(const float *x, float *out, int batch_size, int num_classes, int64_t HxW, unet_stream_t stream);
@@ -392,6 +396,9 @@ int unet_allreduce_begin(unet_comm_t comm, float *data, int64_t count, unet_even
  * averaged in bf16, widened back into `data`): half the bytes on the links and half the time the collective's
  * kernels share the GPU with backward, at bf16 precision of the averaged gradients.  Off by default. */
 int unet_comm_set_bf16_gradients(unet_comm_t comm, int on);
+/* Sizes the bf16 staging buffer for buckets of up to max_count elements, so that unet_allreduce_begin neither
+ * allocates nor synchronises inside a backward pass (call it once after the buckets are known). */
+int unet_comm_reserve_bf16_stage(unet_comm_t comm, int64_t max_count);
 int unet_allreduce_wait(unet_comm_t comm, unet_stream_t stream);
 int unet_allreduce_sum_f32(unet_comm_t comm, float *data, int64_t count, unet_stream_t stream);
 int unet_broadcast_f32(unet_comm_t comm, float *data, int64_t count, int root, unet_stream_t stream);
@@ -434,11 +441,13 @@ int unet_nhwc_bf16_to_nchw_f32(const uint16_t *in, float *out, int N, int C, int
 /* 3x3, padding 1, stride 1 convolution as an implicit GEMM on bf16 MFMA
  * (cudaConvolve, and with w_bwd / bias = NULL the data-gradient half of
  * cudaConvolveBackward).  out = conv(in) + bias, rounded to bf16; when
- * accumulate != 0 the result is added to what `out` holds (gradient fan-in).
+ * accumulate != 0 the result is added to what `out` holds (gradient fan-in; not together with stat_partials).
  * stat_partials (optional) receives rows of partial sums [rows][CoP][2] = (sum, sum of squares) of the
  * rounded outputs over disjoint sets of pixels, rows = unet_conv3x3_stat_rows(N, H, W, CiP, CoP) -- how the
  * pixels are grouped into rows depends on the kernel that serves the shape; consumers add the rows up
- * (unet_bn_finalize_bf16).  unet_conv3x3_stat_tiles(H, W) = number of 16x16 pixel tiles of one image (the
+ * (unet_bn_finalize_bf16).  The count follows the kernel choice at the time of the call: it changes with
+ * unet_conv3x3_pipeline_min_units, never exceeds max(N * unet_conv3x3_stat_tiles(H, W), 1024), and a caller that
+ * allocates once sizes for that bound.  unet_conv3x3_stat_tiles(H, W) = number of 16x16 pixel tiles of one image (the
  * row count per image and phase of the transposed-convolution entry points). */
 int unet_conv3x3_bf16(const uint16_t *in, int in_ld, const uint16_t *w_packed, const float *bias, int co_valid,
                       uint16_t *out, int out_ld, float *stat_partials, int N, int H, int W, int CiP, int CoP,
@@ -446,7 +455,7 @@ int unet_conv3x3_bf16(const uint16_t *in, int in_ld, const uint16_t *w_packed, c
 int unet_conv3x3_stat_rows(int N, int H, int W, int CiP, int CoP);
 /* Two kernels serve the 3x3 entry points with bit-identical outputs: a persistent pipelined one (images of 32
  * rows and more, 64-channel blocks) and a general one.  The pipelined kernel is used when a call has at least
- * this many (32x16 pixel tile, 64-channel block) work units (default 256: one per CU).  Sets the threshold when
+ * this many (32x16 or 16x16 pixel tile, 64-channel block) work units (default 128).  Sets the threshold when
  * min_units >= 0; returns the previous value.  Process-wide; meant for tests and tuning. */
 int unet_conv3x3_pipeline_min_units(int min_units);
 int unet_conv3x3_stat_tiles(int H, int W);

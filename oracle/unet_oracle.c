@@ -484,15 +484,25 @@ void oracle_difference_backward(const float *mask, const float *y, float *dLdY,
 /* Softmax cross-entropy over the channel axis (not in the reference: SOFTMAX
  * is only an enum value, layer.h:31; semantics follow
  * torch.nn.functional.cross_entropy with mean reduction): logits [N,C,H,W],
- * target class per pixel [N,H,W] (int32).  Returns the mean loss; writes
- * dlogits = (softmax - onehot)/(N*H*W) when dlogits != NULL. */
+ * target class per pixel [N,H,W] (int32); a target outside [0, C) marks an
+ * ignored pixel (torch's ignore_index, for every non-class value).  Returns the
+ * mean loss over the V pixels that count; writes dlogits = (softmax - onehot)/V
+ * (zeros at ignored pixels) when dlogits != NULL. */
 float oracle_softmax_xent(const float *logits, const int32_t *target,
                           float *dlogits, int batch, int C, int H, int W) {
   const i64 HW = (i64)H * W;
-  const double inv = 1.0 / ((double)batch * HW);
+  i64 valid = 0;
+  for (i64 p = 0; p < (i64)batch * HW; ++p) valid += target[p] >= 0 && target[p] < C;
+  const double inv = valid > 0 ? 1.0 / (double)valid : 0.0;
   double loss = 0;
   for (int n = 0; n < batch; ++n)
     for (i64 i = 0; i < HW; ++i) {
+      const int t = target[(i64)n * HW + i];
+      if (t < 0 || t >= C) {
+        if (dlogits)
+          for (int c = 0; c < C; ++c) dlogits[((i64)n * C + c) * HW + i] = 0.f;
+        continue;
+      }
       float mx = -INFINITY;
       for (int c = 0; c < C; ++c) {
         const float v = logits[((i64)n * C + c) * HW + i];
@@ -500,7 +510,6 @@ float oracle_softmax_xent(const float *logits, const int32_t *target,
       }
       double se = 0;
       for (int c = 0; c < C; ++c) se += exp((double)logits[((i64)n * C + c) * HW + i] - mx);
-      const int t = target[(i64)n * HW + i];
       loss += log(se) + mx - logits[((i64)n * C + t) * HW + i];
       if (dlogits)
         for (int c = 0; c < C; ++c) {

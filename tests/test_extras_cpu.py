@@ -41,3 +41,26 @@ def test_concat_crop(oracle):
         torch.cat([ta[:, :, oy:oy + hb, ox:ox + wb], tb], dim=1).backward(torch.from_numpy(dy))
         np.testing.assert_array_equal(da, ta.grad.numpy())
         np.testing.assert_array_equal(db, tb.grad.numpy())
+
+
+def test_oracle_cross_entropy_ignores_labels_that_are_no_class():
+    """oracle.softmax_xent against F.cross_entropy(ignore_index) in float64, every non-class label mapped to
+    the ignored value on the torch side."""
+    import torch
+    import torch.nn.functional as F
+    import oracle
+    rng = np.random.default_rng(3)
+    n, c, h, w = 2, 4, 9, 11
+    logits = rng.standard_normal((n, c, h, w)).astype(np.float32) * 2
+    tgt = rng.integers(0, c, (n, h, w)).astype(np.int32)
+    tgt[rng.random(tgt.shape) < 0.25] = 255
+    tgt[rng.random(tgt.shape) < 0.1] = -7
+    x = torch.from_numpy(logits).double().requires_grad_(True)
+    t = torch.from_numpy(np.where((tgt < 0) | (tgt >= c), -100, tgt)).long()
+    ref = F.cross_entropy(x, t, ignore_index=-100)
+    ref.backward()
+    loss, g = oracle.softmax_xent(logits, tgt)
+    assert abs(loss - float(ref)) <= 1e-5 * abs(float(ref))
+    np.testing.assert_allclose(g, x.grad.numpy(), rtol=1e-4, atol=1e-7)
+    loss0, g0 = oracle.softmax_xent(logits, np.full((n, h, w), -1, np.int32))
+    assert loss0 == 0 and not g0.any()

@@ -106,6 +106,37 @@ CONV_CASES = [
 ]
 
 
+def test_conv3x3_stat_rows_match_the_kernel_that_runs(G, capi):
+    """The row count unet_conv3x3_stat_rows promises is the one the call writes, on either side of the pipelined
+    kernel's work threshold; it stays within the documented bound; statistics together with accumulate (whose row
+    count would differ) are rejected."""
+    n, c, h, w = 4, 64, 32, 32
+    rng = np.random.default_rng(5)
+    x = torch.from_numpy(rng.standard_normal((n, h, w, c)).astype(np.float32)).to(G.DEV).bfloat16()
+    fwd, _ = pack(G, capi, bf16_round(rng.standard_normal(c * c * 9) * 0.05), c, c, 3)
+    out = torch.zeros((n, h, w, c), dtype=torch.bfloat16, device=G.DEV)
+    tiles = capi.lib().unet_conv3x3_stat_tiles(h, w)
+    bound = max(n * tiles, 1024)
+    sums = []
+    old = capi.lib().unet_conv3x3_pipeline_min_units(-1)
+    try:
+        for thr in (1, 1 << 30):   # pipelined kernel / general kernel
+            capi.lib().unet_conv3x3_pipeline_min_units(thr)
+            rows = capi.lib().unet_conv3x3_stat_rows(n, h, w, c, c)
+            assert 0 < rows <= bound
+            guard = 8
+            stats = torch.full((rows + guard, c, 2), 7.0, device=G.DEV)
+            capi.unet_conv3x3_bf16(G.p(x), c, G.p(fwd), None, 0, G.p(out), c, G.p(stats), n, h, w, c, c, 0, None)
+            st = stats.cpu().numpy()
+            assert np.all(st[rows:] == 7.0), "rows beyond the promised count were written"
+            sums.append(st[:rows].sum(axis=0))
+            with pytest.raises(RuntimeError, match="accumulate"):
+                capi.unet_conv3x3_bf16(G.p(x), c, G.p(fwd), None, 0, G.p(out), c, G.p(stats), n, h, w, c, c, 1, None)
+    finally:
+        capi.lib().unet_conv3x3_pipeline_min_units(old)
+    assert_close(sums[0], sums[1], rtol=1e-5, atol_scale=1e-6, what="statistics of the two kernels")
+
+
 @pytest.mark.parametrize("cfg", CONV_CASES)
 def test_conv3x3_forward_dgrad_wgrad(G, capi, oracle, cfg):
     n, ci, co, h, w = cfg

@@ -364,6 +364,37 @@ def test_difference_and_xent(G, capi, oracle, golden):
     assert_close(G.host(gl), g_ref, what="cross entropy grad vs oracle")
 
 
+def test_cross_entropy_ignores_labels_that_are_no_class(G, capi, oracle):
+    """Ignore labels (255, -1, anything outside [0, C)) must not index the logits: such pixels add no loss, get
+    a zero gradient and leave the mean (torch's ignore_index, for every value that is not a class)."""
+    rng = np.random.default_rng(10)
+    n, c, h, w = 2, 5, 19, 23
+    logits = (rng.standard_normal((n, c, h, w)) * 2).astype(np.float32)
+    tgt = rng.integers(0, c, (n, h, w)).astype(np.int32)
+    tgt[rng.random(tgt.shape) < 0.2] = 255
+    tgt[rng.random(tgt.shape) < 0.1] = -1
+    tgt[0, 0, 0], tgt[1, 3, 4] = 2 ** 31 - 1, -2 ** 31
+    gl, loss = G.empty(logits.shape), G.empty((1,))
+    ld, td = G.dev(logits), G.dev(tgt)
+    capi.unet_softmax_xent_f32(G.p(ld), G.p(td), G.p(gl), G.p(loss), n, c, h, w, None)
+    l_ref, g_ref = oracle.softmax_xent(logits, tgt)
+    assert_close(G.host(loss)[0], np.float32(l_ref), what="cross entropy with ignored pixels")
+    got = G.host(gl)
+    assert_close(got, g_ref, what="cross entropy grad with ignored pixels")
+    bad = (tgt < 0) | (tgt >= c)
+    assert np.all(got.transpose(0, 2, 3, 1)[bad] == 0)
+    # nothing but ignored pixels: loss 0, gradient 0, no division by zero
+    td2 = G.dev(np.full((n, h, w), 255, np.int32))
+    capi.unet_softmax_xent_f32(G.p(ld), G.p(td2), G.p(gl), G.p(loss), n, c, h, w, None)
+    assert G.host(loss)[0] == 0 and not G.host(gl).any()
+    # labels that arrive as floats: NaN, infinities and values beyond int32 become "no class"
+    f = np.array([0.0, 1.4, 3.6, np.nan, np.inf, -np.inf, 3e9, -3e9, 255.0], np.float32)
+    out = torch.zeros(f.size, dtype=torch.int32, device=G.DEV)
+    fd = G.dev(f)
+    capi.unet_f32_to_i32(G.p(fd), G.p(out), f.size, None)
+    assert out.cpu().tolist() == [0, 1, 4, -1, -1, -1, -1, -1, 255]
+
+
 def test_adam(G, capi, oracle, golden):
     w = G.dev(golden["adam_w0"])
     st = torch.zeros(2 * w.numel(), device=G.DEV)

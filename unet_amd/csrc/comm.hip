@@ -86,6 +86,18 @@ __global__ __launch_bounds__(256) void grad_from_bf16_kernel(const uint16_t *__r
     out[i] = __uint_as_float((uint32_t)in[i] << 16);
 }
 
+// Grows the bf16 staging buffer to `elems` elements (earlier buckets may still use the old one: drain first).
+int reserve_stage(Comm *c, size_t elems) {
+  if (c->stage_elems >= elems) return UNET_OK;
+  UNET_HIP_TRY(hipStreamSynchronize(c->stream));
+  if (c->stage) UNET_HIP_TRY(hipFree(c->stage));
+  c->stage = nullptr;
+  c->stage_elems = 0;
+  UNET_HIP_TRY(hipMalloc((void **)&c->stage, sizeof(uint16_t) * elems));
+  c->stage_elems = elems;
+  return UNET_OK;
+}
+
 // The communicator batch-norm launchers synchronise their statistics over (NULL = per-rank statistics).
 Comm *g_bn_sync = nullptr;
 
@@ -176,13 +188,11 @@ int unet_allreduce_begin(unet_comm_t comm, float *data, int64_t count, unet_even
   if (c->bf16_gradients) {
     // half the bytes on the links and half the time the collective's kernels stay resident: the bucket is
     // rounded to bf16, averaged in bf16 and widened again, all on the communication stream
+    // (unet_comm_reserve_bf16_stage sizes the buffer ahead of time, so that nothing allocates or synchronises
+    // inside a backward pass; a bucket that still outgrows it takes the slow path once)
     if (c->stage_elems < (size_t)count) {
-      UNET_HIP_TRY(hipStreamSynchronize(c->stream));  // earlier buckets may still use the old buffer
-      if (c->stage) UNET_HIP_TRY(hipFree(c->stage));
-      c->stage = nullptr;
-      c->stage_elems = 0;
-      UNET_HIP_TRY(hipMalloc((void **)&c->stage, sizeof(uint16_t) * (size_t)count));
-      c->stage_elems = (size_t)count;
+      int rc = reserve_stage(c, (size_t)count);
+      if (rc) return rc;
     }
     const unsigned blocks = (unsigned)((count + 1023) / 1024 < 4096 ? (count + 1023) / 1024 : 4096);
     hipLaunchKernelGGL(grad_to_bf16_kernel, dim3(blocks), dim3(256), 0, c->stream, (const float *)data, c->stage, (i64)count);
@@ -202,6 +212,12 @@ int unet_comm_set_bf16_gradients(unet_comm_t comm, int on) {
   UNET_REQUIRE(c, "unet_comm_set_bf16_gradients: NULL communicator");
   c->bf16_gradients = on != 0;
   return UNET_OK;
+}
+
+int unet_comm_reserve_bf16_stage(unet_comm_t comm, int64_t max_count) {
+  Comm *c = static_cast<Comm *>(comm);
+  UNET_REQUIRE(c && max_count > 0, "unet_comm_reserve_bf16_stage: bad argument");
+  return reserve_stage(c, (size_t)max_count);
 }
 
 int unet_allreduce_wait(unet_comm_t comm, unet_stream_t stream) {

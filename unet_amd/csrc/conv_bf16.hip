@@ -467,7 +467,7 @@ int narrow_block_workgroups() {
 }
 
 int launch_conv_any(int taps, const ConvArgs &a, hipStream_t s) {
-  if (taps == 9 && pipe::eligible(a.N, a.Ho, a.Wo, a.Ci, a.CoP) && !(a.accumulate && a.stats)) return launch_pipe_from(a, s);
+  if (taps == 9 && pipe::eligible(a.N, a.Ho, a.Wo, a.Ci, a.CoP)) return launch_pipe_from(a, s);
   const bool wide = a.CoP % 64 == 0, deep = a.Ci % 64 == 0;
   // the 16x16x32 path for every image the pipelined kernel could take at some batch size (16 x 16 pixels and
   // more), and for smaller ones with many tiles.  The choice must not depend on the batch size: the two loops
@@ -784,6 +784,9 @@ static int conv3x3_impl(const uint16_t *in, int in_ld, const uint16_t *w_packed,
                         int accumulate, const float4 *affine, unet_stream_t s) {
   UNET_REQUIRE(in && w_packed && out, "unet_conv3x3_bf16: NULL pointer");
   UNET_REQUIRE(N > 0 && N <= 65535 && H > 0 && W > 0, "unet_conv3x3_bf16: bad sizes");
+  // (the statistics describe what this call computed, not the sum it leaves in `out`; and the row count
+  // unet_conv3x3_stat_rows promises holds for plain calls only)
+  UNET_REQUIRE(!(accumulate && stat_partials), "unet_conv3x3_bf16: stat_partials cannot be combined with accumulate");
   UNET_REQUIRE(CiP > 0 && (CiP % 32 == 0 || (CiP < 32 && CiP % 8 == 0)) && CoP > 0 && CoP % 32 == 0 && in_ld >= CiP &&
                    out_ld >= CoP && in_ld % 8 == 0 && out_ld % 8 == 0,
                "unet_conv3x3_bf16: CiP must be a multiple of 32 (or 8, 16, 24 with weights packed for 32), CoP a "

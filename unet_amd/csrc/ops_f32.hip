@@ -205,7 +205,10 @@ __global__ __launch_bounds__(256) void has_nan_kernel(const float *x, i64 n, int
 }
 __global__ __launch_bounds__(256) void f32_to_i32_kernel(const float *__restrict__ in, int32_t *__restrict__ out, i64 n) {
   for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (i64)gridDim.x * blockDim.x)
-    out[i] = (int32_t)lrintf(in[i]);
+  {
+    const float v = in[i];  // NaN, infinities and anything beyond the int32 range: -1 (no class)
+    out[i] = (v >= -2147483648.f && v < 2147483648.f) ? (int32_t)lrintf(v) : -1;
+  }
 }
 // out[n][i] = index of the largest of x[n][0..C)[i] (first on ties), as a float
 __global__ __launch_bounds__(256) void argmax_channels_kernel(const float *__restrict__ x, float *__restrict__ out, int N,
@@ -620,37 +623,63 @@ __global__ __launch_bounds__(256) void dice_bwd_kernel(const float *__restrict__
 }
 
 // ---- softmax cross entropy ---------------------------------------------------------
+// A label outside [0, C) marks its pixel as ignored: no loss, zero gradient, and the mean runs over the other
+// pixels only (what torch's ignore_index does for one value, here for every value that is not a class).
+__global__ __launch_bounds__(256) void xent_count_kernel(const int32_t *__restrict__ target, int *__restrict__ counts,
+                                                         int C, i64 P) {
+  __shared__ int red[4];
+  int n = 0;
+  for (i64 p = (i64)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (i64)gridDim.x * blockDim.x)
+    n += (unsigned)target[p] < (unsigned)C;
+  for (int o = 32; o > 0; o >>= 1) n += __shfl_down(n, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = n;
+  __syncthreads();
+  if (threadIdx.x == 0) counts[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
 __global__ __launch_bounds__(256) void xent_kernel(const float *__restrict__ logits,
                                                    const int32_t *__restrict__ target,
                                                    float *__restrict__ dlogits,
-                                                   float *__restrict__ partial, int C, i64 HW, i64 P,
-                                                   float inv_p) {
+                                                   float *__restrict__ partial, const int *__restrict__ counts,
+                                                   int C, i64 HW, i64 P) {
   __shared__ float red[4];
+  __shared__ float inv_s;
+  if (threadIdx.x == 0) {  // every block adds up the per-block counts of valid labels (at most 1024, in order)
+    i64 valid = 0;
+    for (unsigned b = 0; b < gridDim.x; ++b) valid += counts[b];
+    inv_s = valid > 0 ? 1.0f / (float)valid : 0.f;
+  }
+  __syncthreads();
+  const float inv_p = inv_s;
   float acc[1] = {0.f};
   for (i64 p = (i64)blockIdx.x * blockDim.x + threadIdx.x; p < P; p += (i64)gridDim.x * blockDim.x) {
     const i64 n = p / HW, i = p - n * HW;
     const float *lp = logits + n * C * HW + i;
+    const int t = target[p];
+    const bool valid = (unsigned)t < (unsigned)C;
     float mx = -INFINITY;
     for (int c = 0; c < C; ++c) mx = fmaxf(mx, lp[(i64)c * HW]);
     float se = 0.f;
     for (int c = 0; c < C; ++c) se += expf(lp[(i64)c * HW] - mx);
-    const int t = target[p];
-    acc[0] += logf(se) + mx - lp[(i64)t * HW];
+    if (valid) acc[0] += logf(se) + mx - lp[(i64)t * HW];
     if (dlogits) {
       float *gp = dlogits + n * C * HW + i;
-      const float r = 1.0f / se;
+      const float r = valid ? inv_p / se : 0.f;
       for (int c = 0; c < C; ++c)
-        gp[(i64)c * HW] = (expf(lp[(i64)c * HW] - mx) * r - (c == t ? 1.0f : 0.0f)) * inv_p;
+        gp[(i64)c * HW] = valid ? expf(lp[(i64)c * HW] - mx) * r - (c == t ? inv_p : 0.0f) : 0.f;
     }
   }
   block_sum<1>(acc, red);
   if (threadIdx.x == 0) partial[blockIdx.x] = acc[0];
 }
-__global__ void xent_finalize_kernel(const float *partial, int nblocks, float *loss, float inv_p) {
+__global__ void xent_finalize_kernel(const float *partial, const int *counts, int nblocks, float *loss) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     double s = 0;
-    for (int i = 0; i < nblocks; ++i) s += partial[i];
-    *loss = (float)(s * inv_p);
+    i64 valid = 0;
+    for (int i = 0; i < nblocks; ++i) {
+      s += partial[i];
+      valid += counts[i];
+    }
+    *loss = valid > 0 ? (float)(s / (double)valid) : 0.f;
   }
 }
 
@@ -1172,14 +1201,17 @@ int unet_softmax_xent_f32(const float *logits, const int32_t *target, float *dlo
   unsigned nb = ew_grid(P);
   if (nb > 1024) nb = 1024;
   void *ws;
-  int rc = unet_workspace(&ws, sizeof(float) * nb, as_stream(s));
+  int rc = unet_workspace(&ws, (sizeof(float) + sizeof(int)) * nb, as_stream(s));
   if (rc) return rc;
-  const float inv_p = 1.0f / (float)P;
-  hipLaunchKernelGGL(xent_kernel, dim3(nb), dim3(256), 0, as_stream(s), logits, target, dlogits, (float *)ws, C,
-                     HW, P, inv_p);
+  float *partial = (float *)ws;
+  int *counts = (int *)(partial + nb);
+  hipLaunchKernelGGL(xent_count_kernel, dim3(nb), dim3(256), 0, as_stream(s), target, counts, C, P);
+  UNET_LAUNCH_CHECK("xent_count_kernel");
+  hipLaunchKernelGGL(xent_kernel, dim3(nb), dim3(256), 0, as_stream(s), logits, target, dlogits, partial,
+                     (const int *)counts, C, HW, P);
   UNET_LAUNCH_CHECK("xent_kernel");
-  hipLaunchKernelGGL(xent_finalize_kernel, dim3(1), dim3(64), 0, as_stream(s), (const float *)ws, (int)nb,
-                     loss_out, inv_p);
+  hipLaunchKernelGGL(xent_finalize_kernel, dim3(1), dim3(64), 0, as_stream(s), (const float *)partial, (const int *)counts,
+                     (int)nb, loss_out);
   UNET_LAUNCH_CHECK("xent_finalize_kernel");
   return UNET_OK;
 }

@@ -92,6 +92,16 @@ def library_transport_ready(capi, group=None, device=None):
     return bool(ok), why
 
 
+def all_ranks_agree(ok, group=None, device=None):
+    """True when `ok` holds on every rank of `group` (a MIN over torch.distributed)."""
+    if not (dist.is_initialized() and dist.get_world_size(group) > 1):
+        return bool(ok)
+    on_device = dist.get_backend(group) == "nccl"
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device if on_device else "cpu")
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    return bool(int(flag.item()))
+
+
 class DataParallel:
     """Wraps a created neural_net.NeuralNet for synchronous data-parallel training."""
 
@@ -128,6 +138,14 @@ class DataParallel:
                     self.comm = init_comm(capi, group, device)
                 except RuntimeError as e:
                     failure = str(e)
+                # The set-up can fail on one rank only.  A rank that fell back alone would meet the others in
+                # mismatched collectives and hang them, so the ranks agree on the outcome too; where any of them
+                # failed, all give up the library transport and destroy what they created.
+                if not all_ranks_agree(failure is None, group, device):
+                    if self.comm is not None:
+                        capi.unet_comm_destroy(self.comm)
+                        self.comm = None
+                    failure = failure or "another rank could not set up its communicator"
             if failure is not None:
                 if self.sync_bn:
                     raise RuntimeError(failure)

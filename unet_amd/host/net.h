@@ -337,8 +337,7 @@ class Net {
   // One Adam step over every parameter (cuda_ops.cu:405-471 semantics, one
   // step counter for the whole network).
   void step_device(float learning_rate) {
-    if (comm_) UNET_CALL(unet_allreduce_wait(comm_, stream_));  // every bucket's mean over the ranks has landed
-    flag_nonfinite_gradients();
+    flag_nonfinite_gradients();  // (waits for every bucket's mean over the ranks first)
     ++step_count_;
     UNET_CALL(unet_update_weights_adam_f32(params_.f32(), grads_.f32(), adam_.f32(), learning_rate,
                                            total_params_, step_count_, stream_));
@@ -352,6 +351,7 @@ class Net {
   void set_check_nan(bool on) { check_nan_ = on; }
   bool check_nan() const { return check_nan_; }
   void flag_nonfinite_gradients() {
+    wait_gradients();
     if (!check_nan_) return;
     nan_flag_.ensure(sizeof(int));
     UNET_CALL(unet_flag_nonfinite_f32(grads_.f32(), total_params_, static_cast<int *>(nan_flag_.raw()), step_count_ + 1,
@@ -520,7 +520,16 @@ class Net {
     return (float)(0.5 * s / ((double)batch * f.out_h * f.out_w));
   }
 
-  void sync() { UNET_CALL(unet_stream_synchronize(stream_)); }
+  // With a communicator attached the gradient buckets are averaged on the communication stream; whoever reads
+  // the gradient buffer on the compute stream (or after a host synchronisation) first makes that stream wait
+  // for the reductions issued so far.
+  void wait_gradients() {
+    if (comm_) UNET_CALL(unet_allreduce_wait(comm_, stream_));
+  }
+  void sync() {
+    wait_gradients();
+    UNET_CALL(unet_stream_synchronize(stream_));
+  }
 
   void copy_params_to_host(float *dst) {
     UNET_CALL(unet_memcpy_d2h(dst, params_.raw(), sizeof(float) * (size_t)total_params_, 1, stream_));
@@ -532,6 +541,7 @@ class Net {
     inf_coef_valid_ = false;
   }
   void copy_grads_to_host(float *dst) {
+    wait_gradients();
     UNET_CALL(unet_memcpy_d2h(dst, grads_.raw(), sizeof(float) * (size_t)total_params_, 1, stream_));
   }
   void copy_output_to_host(int layer, float *dst, int batch) {
@@ -572,6 +582,7 @@ class Net {
   void set_bucket_bytes(int64_t bytes) {
     bucket_bytes_ = bytes;
     buckets_.clear();
+    reserve_comm_stage();
   }
   struct Bucket {
     int64_t offset, count;  // in floats
@@ -603,7 +614,18 @@ class Net {
   // Data-parallel training over a communicator of the C ABI (unet_comm_init_rank; NULL = single process):
   // backward_device() then starts the all-reduce of every gradient bucket as it completes and
   // step_device() waits for all of them.
-  void set_comm(unet_comm_t comm) { comm_ = comm; }
+  void set_comm(unet_comm_t comm) {
+    comm_ = comm;
+    reserve_comm_stage();
+  }
+  // room for the largest bucket in the communicator's bf16 staging buffer (used when the buckets travel as bf16),
+  // so that no reduction started from backward has to allocate
+  void reserve_comm_stage() {
+    if (!comm_) return;
+    int64_t largest = 0;
+    for (const Bucket &b : buckets()) largest = std::max<int64_t>(largest, b.count);
+    if (largest > 0) UNET_CALL(unet_comm_reserve_bf16_stage(comm_, largest));
+  }
   unet_comm_t comm() const { return comm_; }
   // Rank `root`'s parameters, running statistics and optimiser state to every rank.
   void broadcast_state(int root) {
@@ -1121,8 +1143,12 @@ class Net {
         n.coef.ensure(sizeof(float) * (size_t)unet_bn_coef_floats(n.cop));
         n.coef_inf.ensure(sizeof(float) * (size_t)unet_bn_coef_floats(n.cop));
         const size_t in_pix_tiles = (size_t)unet_conv3x3_stat_tiles(n.in_h, n.in_w);
-        const size_t parts = n.type == CONV_LAYER ? (size_t)conv_stat_rows(batch, n.in_h, n.in_w, n.cip, n.cop)
-                                                  : 4 * b * in_pix_tiles;
+        // (a convolution's row count follows the kernel that serves the call, which a later change of the
+        // pipelined kernel's work threshold can switch: room for either kernel's rows)
+        const size_t parts = n.type == CONV_LAYER
+                                 ? std::max<size_t>({(size_t)conv_stat_rows(batch, n.in_h, n.in_w, n.cip, n.cop), b * in_pix_tiles,
+                                                     std::min<size_t>(4 * b * in_pix_tiles, 1024)})
+                                 : 4 * b * in_pix_tiles;
         n.stat_partials.ensure(sizeof(float) * parts * n.cop * 2);
         // BN-backward sums arrive from the consumer's data-gradient kernel (a 3x3 convolution over this
         // layer's output grid, a transposed convolution whose input grid it is, or the head): room for the
