@@ -183,6 +183,10 @@ def main():
     ap.add_argument("--base", type=int, default=64, help="channels of the first stage (unet4 graph)")
     ap.add_argument("--graph", default=os.environ.get("UNET_BENCH_GRAPH", "unet4_base64"),
                     choices=["unet4_base64", "mainpy", "attention_unet"])
+    ap.add_argument("--loss", default="dice", choices=["dice", "xent"],
+                    help="dice: the reference's loss on a one-channel sigmoid output; xent: softmax cross-entropy over "
+                         "--classes logits (the final layer gets that many channels)")
+    ap.add_argument("--classes", type=int, default=2)
     ap.add_argument("--infer", action="store_true",
                     help="time the inference forward pass (BASELINE config 2 with --dtype fp32 --batch 1) instead of a train step")
     ap.add_argument("--dtype", default=None, choices=["bf16", "fp32"], help="compute path (default: bf16 where the graph allows)")
@@ -230,14 +234,24 @@ def main():
     free0, _ = torch.cuda.mem_get_info(device)
     net = nn.NeuralNet()
     net.set_seed(1)
-    net.create(torch_ref.to_layer_descs(nn, graph), nn.LossFunction.DICE_LOSS)
+    if args.loss == "xent":   # the final layer's channels become the classes' logits
+        kind, shape, parents, _ = graph[-1]
+        graph[-1] = (kind, shape[:3] + [args.classes] + shape[4:], parents, "logits")
+        descs = torch_ref.to_layer_descs(nn, graph[:-1])
+        descs.append(nn.LayerDesc(nn.LayerType.CONV_LAYER, graph[-1][1], parents, nn.ActivationType.SOFTMAX))
+        net.create(descs, nn.LossFunction.CROSS_ENTROPY_LOSS)
+    else:
+        net.create(torch_ref.to_layer_descs(nn, graph), nn.LossFunction.DICE_LOSS)
     net.reserve(args.batch)
     dtype = net.compute_dtype() if hasattr(net, "compute_dtype") else "f32"
 
     # synthetic data, generated once, resident on the device
     rng = np.random.default_rng(1234 + rank)
     images = torch.from_numpy(rng.standard_normal((args.batch, 3, H, W)).astype(np.float32)).to(device)
-    masks = torch.from_numpy((rng.random((args.batch, H, W)) < 0.03).astype(np.float32)).to(device)
+    if args.loss == "xent":
+        masks = torch.from_numpy(rng.integers(0, args.classes, (args.batch, H, W)).astype(np.float32)).to(device)
+    else:
+        masks = torch.from_numpy((rng.random((args.batch, H, W)) < 0.03).astype(np.float32)).to(device)
     free1, _ = torch.cuda.mem_get_info(device)   # engine buffers + the synthetic batch
     trainer = dp.DataParallel(net, device)
     trainer.broadcast_parameters()
@@ -346,7 +360,12 @@ def main():
         capi.unet_prof_enable(0)
 
     loss = None
-    if rank == 0 and not args.infer:
+    if rank == 0 and not args.infer and args.loss == "xent":
+        lv = torch.zeros(1, device=device)
+        capi.unet_memcpy_d2d(lv.data_ptr(), net.loss_values_ptr(), 4, None)
+        torch.cuda.synchronize(device)
+        loss = float(lv.item())
+    elif rank == 0 and not args.infer:
         lv = torch.zeros(3 * args.batch, device=device)
         capi.unet_memcpy_d2d(lv.data_ptr(), net.loss_values_ptr(), 12 * args.batch, None)
         torch.cuda.synchronize(device)
@@ -369,7 +388,7 @@ def main():
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
         "config": {"workload": f"{args.graph if args.base == 64 else 'unet4_base%d' % args.base} "
-                               f"{'inference forward (BatchNorm with running statistics)' if args.infer else 'train step (fwd+bwd+Adam, BatchNorm, Dice loss)'}, "
+                               f"{'inference forward (BatchNorm with running statistics)' if args.infer else ('train step (fwd+bwd+Adam, BatchNorm, Dice loss)' if args.loss == 'dice' else f'train step (fwd+bwd+Adam, BatchNorm, softmax cross-entropy over {args.classes} classes)')}, "
                                f"batch {args.batch}x3x{H}x{W} per GPU",
                    "global_batch": args.batch * world, "parallelism": f"dp{world}",
                    "parameters": int(net.num_parameters()),

@@ -150,7 +150,11 @@ int unet_batch_norm_train_f32(const float *inputs, float *activations, const flo
  * image instead of the grow-only workspace, and the call performs no hipMalloc / hipFree.  Shapes whose
  * partial sums do not fit (more than unet_batch_norm_train_noalloc_max_partials() (channel, slice) pairs;
  * at most 512 slices per channel are ever used, so any C <= 256 fits) return UNET_ERR_INVALID.  All calls on
- * one GPU share that GPU's array: calls that overlap on one GPU (different streams or threads) race. */
+ * one GPU share that GPU's array: calls that overlap on one GPU (different streams or threads) race.
+ * The first call on each device looks the array's address up (hipGetSymbolAddress, which may load the code
+ * object): make that call outside stream capture; every later call on the device only launches kernels.
+ * With statistics synchronised across ranks (unet_bn_set_sync with a communicator) the entry point returns
+ * UNET_ERR_INVALID: the cross-rank sum needs a staging buffer this variant does not have. */
 int unet_batch_norm_train_noalloc_f32(const float *inputs, float *activations, const float *weights,
                                       float *BN_batch_stats, float *BN_running_stats, int num_channels,
                                       int H, int W, int batch_size, unet_stream_t stream);

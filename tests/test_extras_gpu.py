@@ -230,3 +230,49 @@ def test_cross_entropy_loss_in_the_engine():
     assert 0 < net.last_epoch_loss() < loss
     cls = net.infer(x[0])
     assert cls.shape == (1, 16, 24) and set(np.unique(cls)).issubset(set(range(classes)))
+
+
+@pytest.mark.parametrize("classes", [4, 32])
+def test_cross_entropy_loss_on_the_bf16_path(classes):
+    """The same loss with every hidden channel count a multiple of 32: the graph runs on the bf16 kernels, the
+    final layer's logits land as fp32 [N][C][H][W] (the narrow route) and the softmax cross-entropy, its gradient
+    and the class map are the fp32 kernels' -- against the PyTorch float64 oracle that rounds to bf16 where the
+    engine stores bf16 (loss 2e-3, output and parameter gradients 2e-2), then a few Adam steps."""
+    import neural_net as nn
+    import torch.nn.functional as F
+    graph = torch_ref.main_py_graph(32, 32, 3, 32)
+    kind, shape, parents, _ = graph[-1]
+    graph[-1] = (kind, shape[:3] + [classes] + shape[4:], parents, "logits")
+    descs = torch_ref.to_layer_descs(nn, graph[:-1])
+    descs.append(nn.LayerDesc(nn.LayerType.CONV_LAYER, graph[-1][1], parents, nn.ActivationType.SOFTMAX))
+    net = nn.NeuralNet()
+    net.set_seed(5)
+    net.create(descs, nn.LossFunction.CROSS_ENTROPY_LOSS)
+    assert net.compute_dtype() == "bf16"
+    rng = np.random.default_rng(11)
+    x = rng.standard_normal((4, 3, 32, 32)).astype(np.float32)
+    labels = rng.integers(0, classes, (4, 32, 32)).astype(np.float32)
+    labels[0, :4, :4] = 255          # an ignore label: no loss, no gradient, left out of the mean
+    p0 = net.get_parameters()
+    p0 = (p0 + rng.standard_normal(p0.size).astype(np.float32) * 0.02).astype(np.float32)
+    net.set_parameters(p0)
+    loss = net.train_step(x, labels, 1e-2, False)
+    g = net.get_gradients().astype(np.float64)
+    logits = net.layer_output(len(graph) - 1, 4)
+    params = torch_ref.split_params(graph, p0)
+    acts = torch_ref.forward(graph, params, torch.from_numpy(x).double(), training=True, emulate_bf16=True)
+    target = torch.from_numpy(np.where(labels >= classes, -100, labels)).long()
+    ref = F.cross_entropy(acts[-1], target, ignore_index=-100)
+    ref.backward()
+    ref_g = torch_ref.flat_grads(graph, params)
+    ref_logits = acts[-1].detach().numpy()
+    assert abs(loss - ref.item()) <= 2e-3 * max(1.0, ref.item()), (loss, ref.item())
+    assert np.linalg.norm(logits - ref_logits) <= 2e-2 * np.linalg.norm(ref_logits)
+    rel = np.linalg.norm(g - ref_g) / np.linalg.norm(ref_g)
+    cos = float(g @ ref_g / (np.linalg.norm(g) * np.linalg.norm(ref_g)))
+    assert rel <= 0.15 and cos >= 0.99, (rel, cos)     # the deep-graph bars of tests/test_module_bf16_gpu.py
+    for _ in range(30):
+        last = net.train_step(x, labels, 2e-2, True)
+    assert last < 0.8 * loss, (last, loss)
+    cls = net.infer(x[0])
+    assert cls.shape == (1, 32, 32) and set(np.unique(cls)).issubset(set(range(classes)))

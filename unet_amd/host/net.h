@@ -1062,10 +1062,6 @@ class Net {
   // the activations: a layer feeding a CONCAT writes straight into its slice of
   // the concat buffer, so concat forward and backward move no data.
   bool plan_bf16(std::string &why) {
-    if (loss_ == LossFunction::kCrossEntropyLoss) {
-      why = "the cross-entropy loss runs on the fp32 kernels";
-      return false;
-    }
     for (Node &n : nodes_) {
       n.concat_child = -1;
       n.pool_child = -1;
@@ -1092,10 +1088,17 @@ class Net {
       switch (n.type) {
         case CONV_LAYER:
           if (n.kernel != 3 || n.padding != 1 || n.stride != 1) return why = "a convolution that is not 3x3/pad 1/stride 1", false;
-          if (n.activation == TANH || n.activation == LEAKY_ReLU) return why = "an activation other than ReLU / sigmoid", false;
+          if ((n.activation == TANH || n.activation == LEAKY_ReLU) && !(is_final && (n.out_c % 32 != 0 || loss_ == LossFunction::kCrossEntropyLoss)))
+            return why = "a hidden layer with an activation other than ReLU / sigmoid", false;
           if (n.parents.empty() ? n.in_c > 32 : n.in_c % 32 != 0) return why = "a convolution whose C_in is not a multiple of 32", false;
           if (n.out_c % 32 != 0) {
             if (!is_final || n.out_c > 32) return why = "a hidden convolution whose C_out is not a multiple of 32", false;
+            n.narrow = true;
+          }
+          // cross-entropy reads fp32 logits [N][C][H][W]: the final layer takes the narrow route (its batch norm
+          // and the loss on the fp32 kernels) whatever its channel count, up to one 32-channel block
+          if (is_final && loss_ == LossFunction::kCrossEntropyLoss) {
+            if (n.out_c > 32) return why = "a cross-entropy loss over more than 32 classes", false;
             n.narrow = true;
           }
           break;
@@ -1281,10 +1284,13 @@ class Net {
             UNET_CALL(unet_batch_norm_train_f32(n.z.f32(), n.bn.f32(), gb, n.batch_stats.f32(), n.running.f32(),
                                                 n.out_c, n.out_h, n.out_w, batch, stream_));
           const int64_t out_n = (int64_t)batch * n.out_elems();
-          if (n.activation == SIGMOID)
-            UNET_CALL(unet_sigmoid_f32(n.bn.f32(), n.act.f32(), out_n, stream_));
-          else
-            UNET_CALL(unet_relu_f32(n.bn.f32(), n.act.f32(), out_n, stream_));
+          switch (effective_activation(n)) {
+            case SIGMOID: UNET_CALL(unet_sigmoid_f32(n.bn.f32(), n.act.f32(), out_n, stream_)); break;
+            case TANH: UNET_CALL(unet_tanh_f32(n.bn.f32(), n.act.f32(), out_n, stream_)); break;
+            case LEAKY_ReLU: UNET_CALL(unet_leaky_relu_f32(n.bn.f32(), n.act.f32(), out_n, n.leaky, stream_)); break;
+            case NONE: UNET_CALL(unet_memcpy_d2d(n.act.raw(), n.bn.raw(), sizeof(float) * (size_t)out_n, stream_)); break;
+            default: UNET_CALL(unet_relu_f32(n.bn.f32(), n.act.f32(), out_n, stream_));
+          }
           break;
         }
         if (!inference)
@@ -1358,10 +1364,15 @@ class Net {
           // fp32: activation backward, BN backward, bias gradient; then dz -> NHWC bf16 (padded with zeros)
           const int64_t out_n = (int64_t)batch * n.out_elems();
           float *g2 = scratch_g2_.f32(), *g1 = scratch_g1_.f32();
-          if (n.activation == SIGMOID)
-            UNET_CALL(unet_sigmoid_backward_f32(n.grad_out.f32(), n.act.f32(), g2, out_n, stream_));
-          else
-            UNET_CALL(unet_relu_backward_f32(n.grad_out.f32(), n.bn.f32(), g2, out_n, stream_));
+          switch (effective_activation(n)) {
+            case SIGMOID: UNET_CALL(unet_sigmoid_backward_f32(n.grad_out.f32(), n.act.f32(), g2, out_n, stream_)); break;
+            case TANH: UNET_CALL(unet_tanh_backward_f32(n.grad_out.f32(), n.act.f32(), g2, out_n, stream_)); break;
+            case LEAKY_ReLU:
+              UNET_CALL(unet_leaky_relu_backward_f32(n.grad_out.f32(), n.bn.f32(), g2, out_n, n.leaky, stream_));
+              break;
+            case NONE: g2 = n.grad_out.f32(); break;  // the logits of the cross-entropy loss
+            default: UNET_CALL(unet_relu_backward_f32(n.grad_out.f32(), n.bn.f32(), g2, out_n, stream_));
+          }
           UNET_CALL(unet_batch_norm_backward_f32(g2, n.z.f32(), n.batch_stats.f32(), w + n.num_wb, g1, gw + n.num_wb,
                                                  n.out_c, n.out_h, n.out_w, batch, stream_));
           if (n.head) {
