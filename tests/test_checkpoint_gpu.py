@@ -80,3 +80,32 @@ def test_weights_exchange_with_pytorch_modules():
     ck.from_torch(other, descs, {k: torch.from_numpy(v) for k, v in state.items()})
     assert np.array_equal(other.get_parameters(), net.get_parameters())
     assert np.array_equal(other.forward(x, True), got)
+
+
+def test_weights_exchange_covers_bn_and_fc_layers():
+    """A BN_LAYER travels as BatchNorm2d tensors only, an FC_LAYER as torch.nn.Linear's [out, in] weight and bias."""
+    import neural_net as nn
+    L, T, A = nn.LayerDesc, nn.LayerType, nn.ActivationType
+    descs = [L(T.CONV_LAYER, [8, 8, 3, 4, 3, 1, 1], [], A.SIGMOID), L(T.BN_LAYER, [], [0], A.TANH),
+             L(T.FC_LAYER, [4, 8, 8, 3], [1], A.SOFTMAX)]
+    nets = []
+    for seed in (3, 8):
+        net = nn.NeuralNet()
+        net.set_seed(seed)
+        net.create(descs, nn.LossFunction.CROSS_ENTROPY_LOSS)
+        nets.append(net)
+    a, b = nets
+    rng = np.random.default_rng(2)
+    x = rng.standard_normal((4, 3, 8, 8)).astype(np.float32)
+    a.train_step(x, rng.integers(0, 3, (4, 1, 1)).astype(np.float32), 1e-2, True)   # moves the running statistics
+    state = ck.to_torch(a, descs)
+    assert state["layers.2.fc.weight"].shape == (3, 256) and state["layers.2.fc.bias"].shape == (3,)
+    assert "layers.1.conv.weight" not in state and state["layers.1.bn.running_var"].shape == (4,)
+    lin = torch.nn.Linear(256, 3)
+    lin.load_state_dict({"weight": torch.from_numpy(state["layers.2.fc.weight"]), "bias": torch.from_numpy(state["layers.2.fc.bias"])})
+    ck.from_torch(b, descs, {k: torch.from_numpy(v) for k, v in state.items()})
+    assert np.array_equal(a.get_parameters(), b.get_parameters())
+    got = a.forward(x, True)
+    assert np.array_equal(got, b.forward(x, True))
+    hidden = torch.from_numpy(a.layer_output(1, 4)).reshape(4, 256)
+    np.testing.assert_allclose(got.reshape(4, 3), lin(hidden).detach().numpy(), rtol=2e-4, atol=2e-5)

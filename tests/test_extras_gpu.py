@@ -276,3 +276,89 @@ def test_cross_entropy_loss_on_the_bf16_path(classes):
     assert last < 0.8 * loss, (last, loss)
     cls = net.infer(x[0])
     assert cls.shape == (1, 32, 32) and set(np.unique(cls)).issubset(set(range(classes)))
+
+
+def _torch_bn(x, gb, eps=1e-8):
+    import torch.nn.functional as F
+    return F.batch_norm(x, None, None, gb[0::2], gb[1::2], training=True, eps=eps)
+
+
+def test_bn_layer_and_fc_layer_against_torch():
+    """BN_LAYER and FC_LAYER, which the reference declares and leaves empty (layer.h:58-66): a batch norm of its own
+    with the descriptor's activation, and a fully connected layer over the whole [C,H,W] input -- here as the
+    classification head of a small network under the cross-entropy loss (labels [N,1,1]).  Loss and every parameter
+    gradient against PyTorch float64; then the loss falls under Adam."""
+    import neural_net as nn
+    import torch.nn.functional as F
+    L, T, A = nn.LayerDesc, nn.LayerType, nn.ActivationType
+    classes, n = 5, 6
+    # (a sigmoid on the first layer: a ReLU's exact zeros would tie in the pooling windows, where the engine follows
+    # the reference -- every tied maximum receives the gradient -- and PyTorch picks one)
+    descs = [L(T.CONV_LAYER, [8, 8, 3, 4, 3, 1, 1], [], A.SIGMOID),
+             L(T.BN_LAYER, [], [0], A.TANH),
+             L(T.MAX_POOL_LAYER, [4, 8, 8, 2, 2], [1]),
+             L(T.BN_LAYER, [4, 4, 4], [2]),                       # NONE: no activation
+             L(T.FC_LAYER, [4, 4, 4, 7], [3], A.LEAKY_ReLU, 0.1),
+             L(T.FC_LAYER, [7, 1, 1, classes], [4], A.SOFTMAX)]
+    net = nn.NeuralNet()
+    net.set_seed(2)
+    net.create(descs, nn.LossFunction.CROSS_ENTROPY_LOSS)
+    assert net.compute_dtype() == "f32"
+    assert net.output_shapes() == [[4, 8, 8], [4, 8, 8], [4, 4, 4], [4, 4, 4], [7, 1, 1], [classes, 1, 1]]
+    layout = net.parameter_layout()
+    assert [(i, wb, bn) for i, _, wb, bn in layout] == [(0, 3 * 4 * 9 + 4, 8), (1, 0, 8), (3, 0, 8), (4, 64 * 7 + 7, 0),
+                                                         (5, 7 * classes + classes, 0)]
+    rng = np.random.default_rng(21)
+    x = rng.standard_normal((n, 3, 8, 8)).astype(np.float32)
+    labels = rng.integers(0, classes, (n, 1, 1)).astype(np.float32)
+    p0 = net.get_parameters()
+    p0 = (p0 + rng.standard_normal(p0.size).astype(np.float32) * 0.1).astype(np.float32)
+    net.set_parameters(p0)
+    loss = net.train_step(x, labels, 1e-2, False)
+    g = net.get_gradients().astype(np.float64)
+
+    flat = torch.from_numpy(p0.astype(np.float64)).requires_grad_(True)
+    off = {i: o for i, o, _, _ in layout}
+    w0 = flat[off[0]:off[0] + 108].reshape(3, 4, 3, 3)
+    b0 = flat[off[0] + 108:off[0] + 112]
+    t = F.conv2d(torch.from_numpy(x).double(), w0.permute(1, 0, 2, 3), b0, padding=1)
+    t = torch.sigmoid(_torch_bn(t, flat[off[0] + 112:off[0] + 120]))
+    t = torch.tanh(_torch_bn(t, flat[off[1]:off[1] + 8]))
+    t = F.max_pool2d(t, 2, 2)
+    t = _torch_bn(t, flat[off[3]:off[3] + 8])
+    t = t.reshape(n, 64) @ flat[off[4]:off[4] + 448].reshape(64, 7) + flat[off[4] + 448:off[4] + 455]
+    t = F.leaky_relu(t, 0.1)
+    logits = t @ flat[off[5]:off[5] + 7 * classes].reshape(7, classes) + flat[off[5] + 7 * classes:off[5] + 8 * classes]
+    ref = F.cross_entropy(logits, torch.from_numpy(labels.reshape(n)).long())
+    ref.backward()
+    ref_g = flat.grad.numpy()
+    assert abs(loss - ref.item()) <= 1e-4 * ref.item(), (loss, ref.item())
+    per_layer = {i: float(np.linalg.norm(g[o:o + wb + bn] - ref_g[o:o + wb + bn]) / np.linalg.norm(ref_g[o:o + wb + bn]))
+                 for i, o, wb, bn in layout}
+    assert max(per_layer.values()) <= 1e-3, per_layer
+    for _ in range(40):
+        last = net.train_step(x, labels, 2e-2, True)
+    assert last < 0.6 * loss, (last, loss)
+    # inference uses the running statistics of both kinds of batch norm; the class map has one entry per image
+    cls = net.infer(x[0])
+    assert cls.shape == (1, 1, 1) and 0 <= cls[0, 0, 0] < classes
+
+
+def test_none_can_mean_no_activation(monkeypatch):
+    """NONE on a CONV layer is ReLU, as in the reference (convolution_layer_functions.h:59-65); with
+    UNET_NONE_IS_IDENTITY=1 it means what it says.  One hidden layer whose batch-norm output is half negative."""
+    import neural_net as nn
+    graph = [("conv", [8, 8, 3, 4, 3, 1, 1], [], "relu"), ("conv", [8, 8, 4, 1, 3, 1, 1], [0], "sigmoid")]
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((2, 3, 8, 8)).astype(np.float32)
+    outs = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("UNET_NONE_IS_IDENTITY", flag)
+        net = nn.NeuralNet()
+        net.set_seed(9)
+        net.create(torch_ref.to_layer_descs(nn, graph), nn.LossFunction.DICE_LOSS)
+        net.forward(x, False)
+        outs[flag] = net.layer_output(0, 2)
+    assert outs["0"].min() == 0.0                       # ReLU
+    assert outs["1"].min() < -0.5                       # the batch norm's output itself
+    np.testing.assert_array_equal(np.maximum(outs["1"], 0), outs["0"])

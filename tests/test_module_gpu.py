@@ -118,8 +118,14 @@ def test_create_validation_messages(nn):
     with pytest.raises(RuntimeError, match="cannot have more than one parent"):
         nn.NeuralNet().create([L(T.CONV_LAYER, [8, 8, 3, 4, 3, 1, 1], []), L(T.CONV_LAYER, [8, 8, 4, 4, 3, 1, 1], [0]),
                                L(T.CONV_LAYER, [8, 8, 4, 4, 3, 1, 1], [0, 1])], nn.DICE_LOSS)
-    with pytest.raises(RuntimeError, match="not implemented"):
+    with pytest.raises(RuntimeError, match="FC layers need 4 shape values"):
         nn.NeuralNet().create([L(T.CONV_LAYER, [8, 8, 3, 4, 3, 1, 1], []), L(T.FC_LAYER, [], [0])], nn.DICE_LOSS)
+    with pytest.raises(RuntimeError, match="does not equal output shape of parent"):
+        nn.NeuralNet().create([L(T.CONV_LAYER, [8, 8, 3, 4, 3, 1, 1], []), L(T.FC_LAYER, [4, 8, 7, 2], [0])], nn.DICE_LOSS)
+    with pytest.raises(RuntimeError, match="BN layers need exactly one parent"):
+        nn.NeuralNet().create([L(T.BN_LAYER, [], [])], nn.DICE_LOSS)
+    with pytest.raises(RuntimeError, match="does not equal output shape of parent"):
+        nn.NeuralNet().create([L(T.CONV_LAYER, [8, 8, 3, 4, 3, 1, 1], []), L(T.BN_LAYER, [5, 8, 8], [0])], nn.DICE_LOSS)
     net = nn.NeuralNet()
     with pytest.raises(RuntimeError, match="create"):
         net.train(np.zeros((1, 3, 8, 8), np.float32), np.zeros((1, 8, 8), np.float32), 1e-3, 1, 1)

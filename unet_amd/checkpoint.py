@@ -147,28 +147,41 @@ def attention_from_torch(t):
                            np.asarray(t["psi.bias"], np.float32).reshape(-1)])
 
 
+def _kind(desc):
+    """'conv', 'up', 'attention', 'bn' or 'fc' for a LayerDesc with parameters."""
+    name = getattr(desc.type, "name", str(desc.type))
+    return {"CONV_LAYER": "conv", "UPSAMPLING_LAYER": "up", "ATTENTION_LAYER": "attention", "BN_LAYER": "bn",
+            "FC_LAYER": "fc"}[name.split(".")[-1]]
+
+
 def to_torch(net, descs):
     """descs: the LayerDesc list the network was created from.  Returns numpy arrays keyed like a
-    PyTorch state_dict: layers.<i>.conv.{weight,bias}, layers.<i>.bn.{weight,bias,running_mean,running_var}."""
+    PyTorch state_dict: layers.<i>.conv.{weight,bias}, layers.<i>.bn.{weight,bias,running_mean,running_var};
+    a BN_LAYER has the bn entries only, an FC_LAYER layers.<i>.fc.{weight [out, in], bias} (torch.nn.Linear)."""
     flat = np.asarray(net.get_parameters(), dtype=np.float32)
     parts = split_parameters(flat, net.parameter_layout())
     out = {}
     shapes = net.output_shapes()
     for i, off, nwb, nbn in net.parameter_layout():
-        if nbn == 0:                            # attention gate: parents = [x, g]
-            cx, cg = (shapes[p][0] for p in descs[i].parents)
+        kind, p = _kind(descs[i]), parts[i]
+        if kind == "attention":                 # parents = [x, g]
+            cx, cg = (shapes[q][0] for q in descs[i].parents)
             for key, v in attention_to_torch(flat[off:off + nwb], cx, cg).items():
                 out[f"layers.{i}.{key}"] = v
-    for i, p in parts.items():
-        if p["gamma"].size == 0:
             continue
         shape = list(descs[i].shape)
-        transposed = len(shape) == 5            # UPSAMPLING: [H, W, C_in, C_out, scale]
-        c_in, c_out, k = shape[2], shape[3], shape[4]
-        w, b = layer_to_torch(p["wb"], c_in, c_out, k, transposed)
+        if kind == "fc":                        # [C_in, H_in, W_in, out]: weights [in][out], then the biases
+            n_out = shape[3]
+            out[f"layers.{i}.fc.weight"] = p["wb"][:nwb - n_out].reshape(-1, n_out).T.copy()
+            out[f"layers.{i}.fc.bias"] = p["wb"][nwb - n_out:].copy()
+            continue
+        if kind in ("conv", "up"):
+            transposed = kind == "up"           # UPSAMPLING: [H, W, C_in, C_out, scale]
+            c_in, c_out, k = shape[2], shape[3], shape[4]
+            w, b = layer_to_torch(p["wb"], c_in, c_out, k, transposed)
+            out[f"layers.{i}.conv.weight"] = w
+            out[f"layers.{i}.conv.bias"] = b
         r = np.asarray(net.running_stats(i), dtype=np.float32)
-        out[f"layers.{i}.conv.weight"] = w
-        out[f"layers.{i}.conv.bias"] = b
         out[f"layers.{i}.bn.weight"] = p["gamma"]
         out[f"layers.{i}.bn.bias"] = p["beta"]
         out[f"layers.{i}.bn.running_mean"] = r[0::2].copy()
@@ -182,18 +195,24 @@ def from_torch(net, descs, state):
         return v.detach().cpu().numpy() if hasattr(v, "detach") else np.asarray(v)
     flat = np.asarray(net.get_parameters(), dtype=np.float32).copy()
     for i, off, nwb, nbn in net.parameter_layout():
-        if nbn == 0:                            # attention gate
+        kind = _kind(descs[i])
+        if kind == "attention":
             wb = attention_from_torch({k: arr(state[f"layers.{i}.{k}"]) for k in ATTENTION_KEYS})
             if wb.size != nwb:
                 raise RuntimeError(f"layer {i}: expected {nwb} attention parameters, got {wb.size}")
             flat[off:off + nwb] = wb
             continue
-        shape = list(descs[i].shape)
-        transposed = len(shape) == 5
-        wb = layer_from_torch(arr(state[f"layers.{i}.conv.weight"]), arr(state[f"layers.{i}.conv.bias"]), transposed)
-        if wb.size != nwb:
-            raise RuntimeError(f"layer {i}: expected {nwb} weights and biases, got {wb.size}")
-        flat[off:off + nwb] = wb
+        if kind == "fc":
+            wb = np.concatenate([arr(state[f"layers.{i}.fc.weight"]).T.reshape(-1), arr(state[f"layers.{i}.fc.bias"]).reshape(-1)])
+            if wb.size != nwb:
+                raise RuntimeError(f"layer {i}: expected {nwb} weights and biases, got {wb.size}")
+            flat[off:off + nwb] = wb.astype(np.float32)
+            continue
+        if kind in ("conv", "up"):
+            wb = layer_from_torch(arr(state[f"layers.{i}.conv.weight"]), arr(state[f"layers.{i}.conv.bias"]), kind == "up")
+            if wb.size != nwb:
+                raise RuntimeError(f"layer {i}: expected {nwb} weights and biases, got {wb.size}")
+            flat[off:off + nwb] = wb
         bn = np.empty(nbn, np.float32)
         bn[0::2] = arr(state[f"layers.{i}.bn.weight"])
         bn[1::2] = arr(state[f"layers.{i}.bn.bias"])

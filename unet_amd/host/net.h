@@ -159,6 +159,8 @@ class Net {
     if (!nodes_.empty()) throw std::runtime_error("create() was already called on this network");
     if (desc.empty()) throw std::runtime_error("your network does not have a single output node");
     loss_ = loss;
+    const char *none = std::getenv("UNET_NONE_IS_IDENTITY");
+    none_is_identity_ = none && none[0] && none[0] != '0';
     nodes_.reserve(desc.size());
     for (size_t i = 0; i < desc.size(); ++i) {
       for (int p : desc[i].parents) {
@@ -241,9 +243,10 @@ class Net {
                                    seed * 1000003ull + layer_id, stream_));
         continue;
       }
-      if (!n.has_params()) continue;
+      if (!n.has_params() && n.type != BN_LAYER && n.type != FC_LAYER) continue;
       float *w = params_.f32() + n.param_off;
-      UNET_CALL(unet_init_he_f32(w, n.num_wb - n.out_c, n.fan, seed * 1000003ull + layer_id, stream_));
+      if (n.num_wb > 0) UNET_CALL(unet_init_he_f32(w, n.num_wb - n.out_c, n.fan, seed * 1000003ull + layer_id, stream_));
+      if (n.num_bn == 0) continue;  // (FC layers have no batch norm)
       UNET_CALL(unet_init_bn_f32(w + n.num_wb, n.num_bn, stream_));
       n.running.ensure(sizeof(float) * (size_t)n.num_bn);
       n.batch_stats.ensure(sizeof(float) * (size_t)n.num_bn);
@@ -633,7 +636,7 @@ class Net {
     UNET_CALL(unet_broadcast_f32(comm_, params_.f32(), total_params_, root, stream_));
     UNET_CALL(unet_broadcast_f32(comm_, adam_.f32(), 2 * total_params_, root, stream_));
     for (Node &n : nodes_)
-      if (n.has_params() && n.num_bn > 0) UNET_CALL(unet_broadcast_f32(comm_, n.running.f32(), n.num_bn, root, stream_));
+      if (n.num_bn > 0) UNET_CALL(unet_broadcast_f32(comm_, n.running.f32(), n.num_bn, root, stream_));
     parameters_changed();
   }
   // To be called after the parameter buffer (param_ptr()) was written from outside the engine: the packed
@@ -678,6 +681,7 @@ class Net {
         n.z.ensure(out_bytes);
         n.bn.ensure(out_bytes);
       }
+      if (n.type == BN_LAYER || n.type == FC_LAYER) n.bn.ensure(out_bytes);  // the activation's argument
       n.act.ensure(out_bytes);
       n.grad_out.ensure(out_bytes);
       max_out = std::max(max_out, n.out_elems());
@@ -850,10 +854,43 @@ class Net {
         n.fan = (int64_t)n.c1 + n.c2;
         break;
       }
-      case BN_LAYER:
-        throw std::runtime_error("BN_LAYER is not implemented (batch norm is part of CONV and UPSAMPLING layers)");
-      case FC_LAYER:
-        throw std::runtime_error("FC_LAYER is not implemented");
+      case BN_LAYER: {
+        // A batch norm of its own (the reference declares the type and leaves it empty, layer.h:58-59).
+        // Descriptor: [] (shape from the parent) or [C, H, W]; parameters [gamma0, beta0, ...] like the batch
+        // norm inside CONV layers; the descriptor's activation follows (NONE = none: there is no reference
+        // behaviour to keep for this type).
+        if (n.parents.size() != 1) throw std::runtime_error("BN layers need exactly one parent");
+        if (!s.empty() && s.size() != 3) throw std::runtime_error("BN layers take no shape values, or 3: C, H, W");
+        const Node &p = parent(0);
+        n.in_c = s.empty() ? p.out_c : s[0];
+        n.in_h = s.empty() ? p.out_h : s[1];
+        n.in_w = s.empty() ? p.out_w : s[2];
+        check_parent_shape(n, "BN");
+        n.out_c = n.in_c; n.out_h = n.in_h; n.out_w = n.in_w;
+        n.input_shape = {n.in_c, n.in_h, n.in_w};
+        n.num_wb = 0;
+        n.num_bn = 2 * (int64_t)n.out_c;
+        break;
+      }
+      case FC_LAYER: {
+        // A fully connected layer (declared and left empty in the reference, layer.h:64-65): every output is a
+        // weighted sum of the whole [C, H, W] input.  Descriptor: [C_in, H_in, W_in, out_features]; output
+        // [out_features, 1, 1]; weights [C_in*H_in*W_in][out_features] then the biases, the layout of a 1x1
+        // convolution over a one-pixel image, which is how it runs; no batch norm; activation as for BN layers.
+        if (n.parents.size() > 1) throw std::runtime_error("FC layers cannot have more than one parent");
+        if (s.size() != 4) throw std::runtime_error("FC layers need 4 shape values: C_in, H_in, W_in, out_features");
+        n.in_c = s[0]; n.in_h = s[1]; n.in_w = s[2]; n.out_c = s[3];
+        if (n.in_c < 1 || n.in_h < 1 || n.in_w < 1 || n.out_c < 1) throw std::runtime_error("FC layer: sizes must be positive");
+        if ((int64_t)n.in_c * n.in_h * n.in_w > (1ll << 24))
+          throw std::runtime_error("FC layer: more than 2^24 input features");
+        check_parent_shape(n, "FC");
+        n.out_h = n.out_w = 1;
+        n.input_shape = {n.in_c, n.in_h, n.in_w};
+        n.num_wb = n.in_elems() * n.out_c + n.out_c;
+        n.num_bn = 0;
+        n.fan = n.in_elems();
+        break;
+      }
       default:
         throw std::runtime_error("unknown layer type");
     }
@@ -878,11 +915,39 @@ class Net {
   // upsampling_layer_functions.h:57-65).
   // Under the cross-entropy loss the final layer's SOFTMAX is the identity here (returned as NONE): the
   // softmax is part of the loss.
+  // BN and FC layers, which the reference never built, take their descriptor's activation literally (NONE = none,
+  // SOFTMAX = the logits of the cross-entropy loss).  UNET_NONE_IS_IDENTITY=1 does the same for NONE on CONV and
+  // UPSAMPLING layers: an opt-in, because a graph written for the reference trains with ReLU there.
   Activation_type effective_activation(const Node &n) const {
-    if (n.type == CONV_LAYER && (n.activation == SIGMOID || n.activation == TANH || n.activation == LEAKY_ReLU))
+    if ((n.type == CONV_LAYER || n.type == BN_LAYER || n.type == FC_LAYER) &&
+        (n.activation == SIGMOID || n.activation == TANH || n.activation == LEAKY_ReLU))
       return n.activation;
     if (loss_ == LossFunction::kCrossEntropyLoss && &n == &nodes_[final_]) return NONE;
+    if (n.type == BN_LAYER || n.type == FC_LAYER) return n.activation == ReLU ? ReLU : NONE;
+    if (n.activation == NONE && none_is_identity_) return NONE;
     return ReLU;
+  }
+  void apply_activation(Node &n, int64_t out_n) {  // n.bn -> n.act
+    switch (effective_activation(n)) {
+      case SIGMOID: UNET_CALL(unet_sigmoid_f32(n.bn.f32(), n.act.f32(), out_n, stream_)); break;
+      case TANH: UNET_CALL(unet_tanh_f32(n.bn.f32(), n.act.f32(), out_n, stream_)); break;
+      case LEAKY_ReLU: UNET_CALL(unet_leaky_relu_f32(n.bn.f32(), n.act.f32(), out_n, n.leaky, stream_)); break;
+      case NONE: UNET_CALL(unet_memcpy_d2d(n.act.raw(), n.bn.raw(), sizeof(float) * (size_t)out_n, stream_)); break;
+      default: UNET_CALL(unet_relu_f32(n.bn.f32(), n.act.f32(), out_n, stream_));
+    }
+  }
+  // gradient with respect to the activation's argument: n.grad_out -> the returned pointer (g2, or grad_out itself)
+  float *activation_backward(Node &n, float *g2, int64_t out_n) {
+    switch (effective_activation(n)) {
+      case SIGMOID: UNET_CALL(unet_sigmoid_backward_f32(n.grad_out.f32(), n.act.f32(), g2, out_n, stream_)); break;
+      case TANH: UNET_CALL(unet_tanh_backward_f32(n.grad_out.f32(), n.act.f32(), g2, out_n, stream_)); break;
+      case LEAKY_ReLU:
+        UNET_CALL(unet_leaky_relu_backward_f32(n.grad_out.f32(), n.bn.f32(), g2, out_n, n.leaky, stream_));
+        break;
+      case NONE: return n.grad_out.f32();
+      default: UNET_CALL(unet_relu_backward_f32(n.grad_out.f32(), n.bn.f32(), g2, out_n, stream_));
+    }
+    return g2;
   }
 
   const float *layer_input(const Node &n, const float *images) const {
@@ -915,15 +980,26 @@ class Net {
         else
           UNET_CALL(unet_batch_norm_train_f32(n.z.f32(), n.bn.f32(), gb, n.batch_stats.f32(), n.running.f32(),
                                               n.out_c, n.out_h, n.out_w, batch, stream_));
-        switch (effective_activation(n)) {
-          case SIGMOID: UNET_CALL(unet_sigmoid_f32(n.bn.f32(), n.act.f32(), out_n, stream_)); break;
-          case TANH: UNET_CALL(unet_tanh_f32(n.bn.f32(), n.act.f32(), out_n, stream_)); break;
-          case LEAKY_ReLU: UNET_CALL(unet_leaky_relu_f32(n.bn.f32(), n.act.f32(), out_n, n.leaky, stream_)); break;
-          case NONE: UNET_CALL(unet_memcpy_d2d(n.act.raw(), n.bn.raw(), sizeof(float) * (size_t)out_n, stream_)); break;
-          default: UNET_CALL(unet_relu_f32(n.bn.f32(), n.act.f32(), out_n, stream_));
-        }
+        apply_activation(n, out_n);
         break;
       }
+      case BN_LAYER: {
+        const float *gb = params_.f32() + n.param_off;
+        const float *in = layer_input(n, images);
+        if (inference)
+          UNET_CALL(unet_batch_norm_inference_f32(in, n.bn.f32(), gb, n.running.f32(), n.out_h, n.out_w, n.out_c, batch,
+                                                  stream_));
+        else
+          UNET_CALL(unet_batch_norm_train_f32(in, n.bn.f32(), gb, n.batch_stats.f32(), n.running.f32(), n.out_c,
+                                              n.out_h, n.out_w, batch, stream_));
+        apply_activation(n, out_n);
+        break;
+      }
+      case FC_LAYER:  // a 1x1 convolution over a one-pixel image with C_in * H_in * W_in channels
+        UNET_CALL(unet_convolve_f32(params_.f32() + n.param_off, layer_input(n, images), n.bn.f32(), out_n, batch, 1,
+                                    (int)n.in_elems(), n.out_c, 1, 1, 1, 1, 0, 1, stream_));
+        apply_activation(n, out_n);
+        break;
       case MAX_POOL_LAYER:
         UNET_CALL(unet_max_pool_f32(layer_input(n, images), n.act.f32(), batch, n.stride, n.kernel, n.in_c, n.in_h,
                                     n.in_w, stream_));
@@ -966,16 +1042,8 @@ class Net {
         const float *in = layer_input(n, images);
         const float *w = params_.f32() + n.param_off;
         float *gw = grads_.f32() + n.param_off;
-        float *g2 = scratch_g2_.f32(), *g1 = scratch_g1_.f32();
-        switch (effective_activation(n)) {
-          case SIGMOID: UNET_CALL(unet_sigmoid_backward_f32(n.grad_out.f32(), n.act.f32(), g2, out_n, stream_)); break;
-          case TANH: UNET_CALL(unet_tanh_backward_f32(n.grad_out.f32(), n.act.f32(), g2, out_n, stream_)); break;
-          case LEAKY_ReLU:
-            UNET_CALL(unet_leaky_relu_backward_f32(n.grad_out.f32(), n.bn.f32(), g2, out_n, n.leaky, stream_));
-            break;
-          case NONE: UNET_CALL(unet_memcpy_d2d(g2, n.grad_out.raw(), sizeof(float) * (size_t)out_n, stream_)); break;
-          default: UNET_CALL(unet_relu_backward_f32(n.grad_out.f32(), n.bn.f32(), g2, out_n, stream_));
-        }
+        float *g1 = scratch_g1_.f32();
+        const float *g2 = activation_backward(n, scratch_g2_.f32(), out_n);
         UNET_CALL(unet_batch_norm_backward_f32(g2, n.z.f32(), n.batch_stats.f32(), w + n.num_wb, g1, gw + n.num_wb,
                                                n.out_c, n.out_h, n.out_w, batch, stream_));
         float *dx = nullptr;
@@ -987,6 +1055,26 @@ class Net {
         else
           UNET_CALL(unet_upsample_backward_f32(g1, in, w, dx, gw, n.kernel, n.in_c, n.out_c, n.in_h, n.in_w, batch,
                                                stream_));
+        if (p) grad_commit(*p, dx, in_n);
+        break;
+      }
+      case BN_LAYER: {
+        Node &p = nodes_[n.parents[0]];
+        const float *g2 = activation_backward(n, scratch_g2_.f32(), out_n);
+        float *dx = grad_target(p);
+        UNET_CALL(unet_batch_norm_backward_f32(g2, p.act.f32(), n.batch_stats.f32(), params_.f32() + n.param_off, dx,
+                                               grads_.f32() + n.param_off, n.out_c, n.out_h, n.out_w, batch, stream_));
+        grad_commit(p, dx, in_n);
+        break;
+      }
+      case FC_LAYER: {
+        const float *g2 = activation_backward(n, scratch_g2_.f32(), out_n);
+        float *dx = nullptr;
+        Node *p = n.parents.empty() ? nullptr : &nodes_[n.parents[0]];
+        if (p) dx = grad_target(*p);
+        UNET_CALL(unet_convolve_backward_f32(g2, layer_input(n, images), params_.f32() + n.param_off, dx,
+                                             grads_.f32() + n.param_off, batch, 1, (int)n.in_elems(), n.out_c, 1, 1, 1, 1, 0,
+                                             1, stream_));
         if (p) grad_commit(*p, dx, in_n);
         break;
       }
@@ -1062,6 +1150,11 @@ class Net {
   // the activations: a layer feeding a CONCAT writes straight into its slice of
   // the concat buffer, so concat forward and backward move no data.
   bool plan_bf16(std::string &why) {
+    if (none_is_identity_)
+      for (size_t i = 0; i < nodes_.size(); ++i)
+        if (nodes_[i].has_params() && nodes_[i].activation == NONE &&
+            !((int)i == final_ && loss_ == LossFunction::kCrossEntropyLoss))
+          return why = "a layer without activation (UNET_NONE_IS_IDENTITY)", false;
     for (Node &n : nodes_) {
       n.concat_child = -1;
       n.pool_child = -1;
@@ -1284,13 +1377,7 @@ class Net {
             UNET_CALL(unet_batch_norm_train_f32(n.z.f32(), n.bn.f32(), gb, n.batch_stats.f32(), n.running.f32(),
                                                 n.out_c, n.out_h, n.out_w, batch, stream_));
           const int64_t out_n = (int64_t)batch * n.out_elems();
-          switch (effective_activation(n)) {
-            case SIGMOID: UNET_CALL(unet_sigmoid_f32(n.bn.f32(), n.act.f32(), out_n, stream_)); break;
-            case TANH: UNET_CALL(unet_tanh_f32(n.bn.f32(), n.act.f32(), out_n, stream_)); break;
-            case LEAKY_ReLU: UNET_CALL(unet_leaky_relu_f32(n.bn.f32(), n.act.f32(), out_n, n.leaky, stream_)); break;
-            case NONE: UNET_CALL(unet_memcpy_d2d(n.act.raw(), n.bn.raw(), sizeof(float) * (size_t)out_n, stream_)); break;
-            default: UNET_CALL(unet_relu_f32(n.bn.f32(), n.act.f32(), out_n, stream_));
-          }
+          apply_activation(n, out_n);
           break;
         }
         if (!inference)
@@ -1364,15 +1451,7 @@ class Net {
           // fp32: activation backward, BN backward, bias gradient; then dz -> NHWC bf16 (padded with zeros)
           const int64_t out_n = (int64_t)batch * n.out_elems();
           float *g2 = scratch_g2_.f32(), *g1 = scratch_g1_.f32();
-          switch (effective_activation(n)) {
-            case SIGMOID: UNET_CALL(unet_sigmoid_backward_f32(n.grad_out.f32(), n.act.f32(), g2, out_n, stream_)); break;
-            case TANH: UNET_CALL(unet_tanh_backward_f32(n.grad_out.f32(), n.act.f32(), g2, out_n, stream_)); break;
-            case LEAKY_ReLU:
-              UNET_CALL(unet_leaky_relu_backward_f32(n.grad_out.f32(), n.bn.f32(), g2, out_n, n.leaky, stream_));
-              break;
-            case NONE: g2 = n.grad_out.f32(); break;  // the logits of the cross-entropy loss
-            default: UNET_CALL(unet_relu_backward_f32(n.grad_out.f32(), n.bn.f32(), g2, out_n, stream_));
-          }
+          g2 = activation_backward(n, g2, out_n);  // (NONE: the logits of the cross-entropy loss)
           UNET_CALL(unet_batch_norm_backward_f32(g2, n.z.f32(), n.batch_stats.f32(), w + n.num_wb, g1, gw + n.num_wb,
                                                  n.out_c, n.out_h, n.out_w, batch, stream_));
           if (n.head) {
@@ -1549,6 +1628,7 @@ class Net {
   DeviceBuffer dz16_;     // scratch: gradient w.r.t. a layer's pre-BN output
   bool verbose_ = true;
   bool check_nan_ = false;
+  bool none_is_identity_ = false;  // UNET_NONE_IS_IDENTITY=1: NONE on CONV / UPSAMPLING layers means no activation
   DeviceBuffer nan_flag_;
   unet_stream_t stream_ = nullptr;
   int64_t bucket_bytes_ = 8 << 20;
