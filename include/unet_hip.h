@@ -553,6 +553,10 @@ int unet_bn_inference_coef_bf16(const float *gamma_beta, const float *running_st
  * concat buffer (y_ld > CoP). */
 int unet_bn_act_bf16(const uint16_t *z, int z_ld, uint16_t *y, int y_ld, const float *coef, int CoP,
                      int64_t pixels, int act, unet_stream_t stream);
+/* The same with the activations the reference declares but runs as ReLU (layer.h:31): act 3 = LEAKY_ReLU with
+ * slope act_param, act 4 = TANH (act 0..2 as above; act_param is ignored for them). */
+int unet_bn_act_ex_bf16(const uint16_t *z, int z_ld, uint16_t *y, int y_ld, const float *coef, int CoP,
+                        int64_t pixels, int act, float act_param, unet_stream_t stream);
 /* cudaReluBackward|cudaSigmoidBackward + cudaBatchNormBackward fused: the
  * incoming gradient is dy1 (+ dy2 when not NULL: gradient fan-in of a layer
  * with two consumers, replacing cudaAddBtoA); writes dz (bf16), grad_gb[2C]
@@ -560,6 +564,11 @@ int unet_bn_act_bf16(const uint16_t *z, int z_ld, uint16_t *y, int y_ld, const f
 int unet_bn_act_backward_bf16(const uint16_t *dy1, int ld1, const uint16_t *dy2, int ld2, const uint16_t *z, int z_ld,
                               const float *coef, const float *gamma_beta, uint16_t *dz, int dz_ld, float *grad_gb,
                               float *grad_bias, int C, int CoP, int64_t pixels, int act, unet_stream_t stream);
+/* unet_bn_act_backward_bf16 for act 0..4 (3 = LEAKY_ReLU with slope act_param, 4 = TANH). */
+int unet_bn_act_backward_ex_bf16(const uint16_t *dy1, int ld1, const uint16_t *dy2, int ld2, const uint16_t *z, int z_ld,
+                                 const float *coef, const float *gamma_beta, uint16_t *dz, int dz_ld, float *grad_gb,
+                                 float *grad_bias, int C, int CoP, int64_t pixels, int act, float act_param,
+                                 unet_stream_t stream);
 
 /* The same with the reduction pass already done by the kernel that produced
  * dy (unet_conv3x3_dgrad_bnred_bf16 / unet_tconv2x2_dgrad_bnred_bf16):

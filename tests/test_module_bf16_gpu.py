@@ -61,11 +61,24 @@ def _make(nn, graph, loss=None, seed=3, dtype=None):
     return net
 
 
+def _with_acts(graph, hidden):
+    """The graph with its hidden convolutions' activations cycling through `hidden` (the last layer keeps its own)."""
+    out, k = [], 0
+    for i, (kind, s, parents, act) in enumerate(graph):
+        if kind == "conv" and i != len(graph) - 1:
+            act = hidden[k % len(hidden)]
+            k += 1
+        out.append((kind, s, parents, act))
+    return out
+
+
 GRAPHS = {
     # conv(3->32)+BN+ReLU -> conv(32->1)+BN+sigmoid: one hidden ReLU layer
     "shallow": lambda: [("conv", [32, 48, 3, 32, 3, 1, 1], [], "relu"), ("conv", [32, 48, 32, 1, 3, 1, 1], [0], "sigmoid")],
     "mainpy32": lambda: torch_ref.main_py_graph(32, 48, 3, 32),
     "unet2_double": lambda: torch_ref.unet_graph(32, 32, 3, 32, 2, True),
+    # LEAKY_ReLU (with its slope) and TANH on the hidden convolutions: the fused bf16 batch-norm kernels' act 3 and 4
+    "mainpy32_leaky_tanh": lambda: _with_acts(torch_ref.main_py_graph(32, 48, 3, 32), ["leaky:0.1", "tanh", "relu"]),
 }
 
 

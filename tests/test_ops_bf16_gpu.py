@@ -313,9 +313,33 @@ def nchw(t, c):
 # the last case is large enough (>= 32 MB per pass) for the streaming variants of the kernels: non-temporal loads
 # and stores, one contiguous piece of the tensor per workgroup
 @pytest.mark.parametrize("cfg", [(2, 64, 16, 16, 0), (1, 32, 9, 7, 0), (3, 96, 8, 8, 0), (2, 32, 8, 8, 1),
-                                 (1, 256, 4, 4, 2), (2, 24, 6, 6, 0), (3, 64, 250, 254, 0)])
+                                 (1, 256, 4, 4, 2), (2, 24, 6, 6, 0), (3, 64, 250, 254, 0),
+                                 # LEAKY_ReLU (slope 0.1) and TANH, through the entry points that take the slope
+                                 (2, 64, 16, 16, 3), (1, 32, 9, 7, 4), (2, 40, 8, 8, 3), (3, 64, 250, 254, 4)])
 def test_bn_act_forward_backward(G, capi, oracle, cfg):
     n, c, h, w, act = cfg
+    slope = 0.1
+    fwd_fn = [oracle.relu, oracle.sigmoid, lambda v: v, lambda v: oracle.leaky_relu(v, slope), oracle.tanh][act]
+
+    def bwd_fn(dy, bn):
+        if act == 0:
+            return oracle.relu_backward(dy, bn)
+        if act == 1:
+            return oracle.sigmoid_backward(dy, oracle.sigmoid(bn))
+        if act == 3:
+            return oracle.leaky_relu_backward(dy, bn, slope)
+        if act == 4:
+            return oracle.tanh_backward(dy, oracle.tanh(bn))
+        return dy
+
+    def bn_act(*a):
+        return capi.unet_bn_act_bf16(*a[:-1], act, None) if act <= 2 else capi.unet_bn_act_ex_bf16(*a[:-1], act, slope, None)
+
+    def bn_act_backward(*a):
+        if act <= 2:
+            return capi.unet_bn_act_backward_bf16(*a, act, None)
+        return capi.unet_bn_act_backward_ex_bf16(*a, act, slope, None)
+
     cop = (c + 7) // 8 * 8
     rng = np.random.default_rng(c * 10 + act)
     z = bf16_round(rng.standard_normal((n, c, h, w)) * 1.3 + 0.4)
@@ -335,9 +359,9 @@ def test_bn_act_forward_backward(G, capi, oracle, cfg):
     stats, coef = G.empty((2 * c,)), G.empty((capi.lib().unet_bn_coef_floats(cop),))
     capi.unet_bn_finalize_bf16(G.p(pd), 2, c, cop, M, G.p(gbd), G.p(stats), G.p(rund), G.p(coef), None)
     y = torch.full((n, h, w, cop + 8), 3.0, dtype=torch.bfloat16, device=G.DEV)   # y is a slice of a wider buffer
-    capi.unet_bn_act_bf16(G.p(zt), cop, y.data_ptr() + 16, cop + 8, G.p(coef), cop, n * h * w, act, None)
+    bn_act(G.p(zt), cop, y.data_ptr() + 16, cop + 8, G.p(coef), cop, n * h * w, None)
     bn_ref, stats_ref, run_ref = oracle.bn_train(z, gb, run_in)
-    y_ref = [oracle.relu, oracle.sigmoid, lambda v: v][act](bn_ref)
+    y_ref = fwd_fn(bn_ref)
     yh = y.float().cpu().numpy()
     assert np.all(yh[..., :8] == 3.0)
     assert_close_bf16(yh[..., 8:8 + c].transpose(0, 3, 1, 2), y_ref, what=f"bn+act forward {cfg}")
@@ -348,15 +372,10 @@ def test_bn_act_forward_backward(G, capi, oracle, cfg):
     d1, d2 = nhwc_tensor(G, dy1, cop), nhwc_tensor(G, dy2, cop)
     dz = torch.full((n, h, w, cop), float("nan"), dtype=torch.bfloat16, device=G.DEV)
     ggb, gbias = G.empty((2 * c,)), G.empty((c,))
-    capi.unet_bn_act_backward_bf16(G.p(d1), cop, G.p(d2), cop, G.p(zt), cop, G.p(coef), G.p(gbd), G.p(dz), cop,
-                                   G.p(ggb), G.p(gbias), c, cop, n * h * w, act, None)
+    bn_act_backward(G.p(d1), cop, G.p(d2), cop, G.p(zt), cop, G.p(coef), G.p(gbd), G.p(dz), cop,
+                    G.p(ggb), G.p(gbias), c, cop, n * h * w)
     dy = dy1 + dy2
-    if act == 0:
-        g = oracle.relu_backward(dy, bn_ref)
-    elif act == 1:
-        g = oracle.sigmoid_backward(dy, oracle.sigmoid(bn_ref))
-    else:
-        g = dy
+    g = bwd_fn(dy, bn_ref)
     dz_ref, ggb_ref = oracle.bn_backward(z, g, gb, stats_ref)
     got = nchw(dz, c)
     assert_close_bf16(got, dz_ref, what=f"bn+act backward {cfg}")
@@ -365,10 +384,9 @@ def test_bn_act_forward_backward(G, capi, oracle, cfg):
     assert_close(G.host(gbias), got.astype(np.float64).sum(axis=(0, 2, 3)), rtol=1e-4, atol_scale=1e-4,
                  what="bias gradient = sum of dz")
     # single-source variant
-    capi.unet_bn_act_backward_bf16(G.p(d1), cop, None, 0, G.p(zt), cop, G.p(coef), G.p(gbd), G.p(dz), cop,
-                                   G.p(ggb), None, c, cop, n * h * w, act, None)
-    g1 = [lambda: oracle.relu_backward(dy1, bn_ref), lambda: oracle.sigmoid_backward(dy1, oracle.sigmoid(bn_ref)),
-          lambda: dy1][act]()
+    bn_act_backward(G.p(d1), cop, None, 0, G.p(zt), cop, G.p(coef), G.p(gbd), G.p(dz), cop,
+                    G.p(ggb), None, c, cop, n * h * w)
+    g1 = bwd_fn(dy1, bn_ref)
     dz1_ref, _ = oracle.bn_backward(z, g1, gb, stats_ref)
     assert_close_bf16(nchw(dz, c), dz1_ref, what=f"bn+act backward, one source {cfg}")
 

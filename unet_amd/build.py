@@ -92,11 +92,22 @@ def build_module(force=False, verbose=False):
     if not srcs:
         return None
     deps = srcs + glob.glob(os.path.join(HOST, "*.h")) + glob.glob(os.path.join(ROOT, "include", "*.h"))
+    # UNET_ASAN=1: the host module with AddressSanitizer (host code only).  Use it with
+    #   LD_PRELOAD="$(g++ -print-file-name=libasan.so) $(g++ -print-file-name=libstdc++.so)" ASAN_OPTIONS=detect_leaks=0
+    #   PYTHONPATH=build/asan:. python -m pytest tests/test_module_cpu.py
+    # (libstdc++ is preloaded too: python does not link it, and the sanitizer's __cxa_throw hook needs the real one).  The sanitized module goes to
+    # build/asan/ so that it never replaces the one the GPU runs load.
+    asan = os.environ.get("UNET_ASAN", "0") not in ("", "0")
+    if asan:
+        os.makedirs(os.path.join(ROOT, "build", "asan"), exist_ok=True)
+        target = os.path.join(ROOT, "build", "asan", os.path.basename(target))
     if force or _newer(target, deps) or _newer(target, [HIP_LIB]):
-        cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-Wall",
+        cmd = ["g++", "-O1", "-g", "-fsanitize=address", "-fno-omit-frame-pointer"] if asan else ["g++", "-O2"]
+        cmd += ["-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-Wall",
                "-I" + pybind11.get_include(), "-I" + sysconfig.get_paths()["include"],
                "-I" + os.path.join(ROOT, "include"), "-I" + HOST] + srcs + \
-              ["-L" + LIBDIR, "-lunet_hip", "-Wl,-rpath,$ORIGIN/unet_amd/lib", "-o", target]
+              ["-L" + LIBDIR, "-lunet_hip", "-Wl,-rpath," + ("$ORIGIN/../../unet_amd/lib" if asan else "$ORIGIN/unet_amd/lib"),
+               "-o", target]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

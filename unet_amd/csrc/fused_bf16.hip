@@ -155,14 +155,22 @@ __global__ void bn_inference_coef_kernel(const float *__restrict__ gb, const flo
   out[c] = r;
 }
 
-// y = act(a*z + b), 8 channels per lane.  ACT: 0 ReLU, 1 sigmoid, 2 identity.
+// y = act(a*z + b), 8 channels per lane.  ACT: 0 ReLU, 1 sigmoid, 2 identity, 3 leaky ReLU (slope ap), 4 tanh.
+template <int ACT>
+__device__ __forceinline__ float act_value(float t, float ap) {
+  if (ACT == 0) return t > 0.f ? t : 0.f;
+  if (ACT == 1) return 1.0f / (1.0f + __expf(-t));
+  if (ACT == 3) return t > 0.f ? t : ap * t;
+  if (ACT == 4) return 1.0f - 2.0f / (1.0f + __expf(2.0f * t));
+  return t;
+}
 // A lane keeps its channel group for all of its pixels, so the 16 coefficients
 // live in registers.  A workgroup owns `ppb` consecutive pixels (a contiguous piece of the tensor when the
 // pixel stride equals the channel count).
 template <int ACT, int NT>  // NT bit 0: non-temporal loads, bit 1: non-temporal stores
 __global__ __launch_bounds__(256) void bn_act_kernel(const bf16_t *__restrict__ z, int z_ld, bf16_t *__restrict__ y,
                                                      int y_ld, const ChanFwd *__restrict__ cf, int CG, int PL,
-                                                     i64 pixels, i64 ppb) {
+                                                     i64 pixels, i64 ppb, float ap) {
   const int cg = threadIdx.x % CG, pl = threadIdx.x / CG;
   if (pl >= PL) return;
   float ca[8], cb[8];
@@ -177,10 +185,7 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const bf16_t *__restrict__ 
     unpack8(in, v);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      float t = fmaf(ca[j], v[j], cb[j]);
-      if (ACT == 0) t = t > 0.f ? t : 0.f;
-      if (ACT == 1) t = 1.0f / (1.0f + __expf(-t));
-      v[j] = t;
+      v[j] = act_value<ACT>(fmaf(ca[j], v[j], cb[j]), ap);
     }
     return pack8(v);
   };
@@ -200,11 +205,16 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const bf16_t *__restrict__ 
 // ---- backward -------------------------------------------------------------------
 // g = (dy1 + dy2) * act'(.)   with act' from the recomputed BN output a*z + b
 template <int ACT>
-__device__ __forceinline__ float act_grad(float dy, float t) {
+__device__ __forceinline__ float act_grad(float dy, float t, float ap = 0.f) {
   if (ACT == 0) return t > 0.f ? dy : 0.f;
   if (ACT == 1) {
     const float s = 1.0f / (1.0f + __expf(-t));
     return dy * s * (1.0f - s);
+  }
+  if (ACT == 3) return t > 0.f ? dy : ap * dy;
+  if (ACT == 4) {
+    const float y = 1.0f - 2.0f / (1.0f + __expf(2.0f * t));
+    return dy * (1.0f - y * y);
   }
   return dy;
 }
@@ -216,7 +226,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const bf16_t *__rest
                                                             const bf16_t *__restrict__ z, int z_ld,
                                                             const ChanFwd *__restrict__ cf, int CG, int PL,
                                                             i64 pixels, i64 ppb, float *__restrict__ partial,
-                                                            int CoP) {
+                                                            int CoP, float ap) {
   extern __shared__ float red[];  // [PL][CG*16]
   const int tid = threadIdx.x;
   const int cg = tid % CG, pl = tid / CG;
@@ -241,7 +251,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const bf16_t *__rest
       unpack8(rz, zv);
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const float gj = act_grad<ACT>(g[j], fmaf(c[j].a, zv[j], c[j].b));
+        const float gj = act_grad<ACT>(g[j], fmaf(c[j].a, zv[j], c[j].b), ap);
         s[2 * j] += gj * ((zv[j] - c[j].mean) * c[j].invb);
         s[2 * j + 1] += gj;
       }
@@ -311,7 +321,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16_t *__restr
                                                            const ChanFwd *__restrict__ cf,
                                                            const ChanBwd *__restrict__ cb, bf16_t *__restrict__ dz,
                                                            int dz_ld, int CG, int PL, i64 pixels, i64 ppb,
-                                                           float *__restrict__ partial, int CoP) {
+                                                           float *__restrict__ partial, int CoP, float ap) {
   extern __shared__ float red[];  // [PL][CG*8]
   const int tid = threadIdx.x;
   const int cg = tid % CG, pl = tid / CG;
@@ -340,7 +350,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16_t *__restr
       unpack8(rz, zv);
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const float gj = act_grad<ACT>(g[j], fmaf(c[j].a, zv[j], c[j].b));
+        const float gj = act_grad<ACT>(g[j], fmaf(c[j].a, zv[j], c[j].b), ap);
         const float xh = (zv[j] - c[j].mean) * c[j].invb;
         o[j] = b[j].c0 * (gj - b[j].k1 - xh * b[j].k2);
       }
@@ -855,10 +865,16 @@ int unet_bn_inference_coef_bf16(const float *gamma_beta, const float *running_st
 
 int unet_bn_act_bf16(const uint16_t *z, int z_ld, uint16_t *y, int y_ld, const float *coef, int CoP,
                      int64_t pixels, int act, unet_stream_t s) {
+  UNET_REQUIRE(act >= 0 && act <= 2, "unet_bn_act_bf16: act must be 0 (ReLU), 1 (sigmoid) or 2 (identity)");
+  return unet_bn_act_ex_bf16(z, z_ld, y, y_ld, coef, CoP, pixels, act, 0.f, s);
+}
+
+int unet_bn_act_ex_bf16(const uint16_t *z, int z_ld, uint16_t *y, int y_ld, const float *coef, int CoP,
+                        int64_t pixels, int act, float act_param, unet_stream_t s) {
   int rc = check_view("unet_bn_act_bf16 (z)", z, z_ld, CoP);
   if (!rc) rc = check_view("unet_bn_act_bf16 (y)", y, y_ld, CoP);
   if (rc) return rc;
-  UNET_REQUIRE(coef && CoP > 0 && CoP % 8 == 0 && CoP <= 2048 && pixels > 0 && act >= 0 && act <= 2,
+  UNET_REQUIRE(coef && CoP > 0 && CoP % 8 == 0 && CoP <= 2048 && pixels > 0 && act >= 0 && act <= 4,
                "unet_bn_act_bf16: bad argument (CoP must be a multiple of 8, at most 2048)");
   const RedPlan pl = plan_stream(CoP, pixels, 4, stream_trips());
   const dim3 grid(pl.blocks);
@@ -867,13 +883,15 @@ int unet_bn_act_bf16(const uint16_t *z, int z_ld, uint16_t *y, int y_ld, const f
   ProfScope prof(PROF_BN_ACT_BF16, 0, bytes, as_stream(s));
 #define ACT_LAUNCH(ACT_, NT_)                                                                                   \
   hipLaunchKernelGGL((bn_act_kernel<ACT_, NT_>), grid, dim3(256), 0, as_stream(s), z, z_ld, y, y_ld, cf, pl.CG, \
-                     pl.PL, (i64)pixels, pl.ppb)
+                     pl.PL, (i64)pixels, pl.ppb, act_param)
   static const int lab_mask = getenv("UNET_LAB_BN_ACT_NT_MASK") ? atoi(getenv("UNET_LAB_BN_ACT_NT_MASK")) : 1;  // laboratory switch
   const int mask = stream_nontemporal(bytes) ? lab_mask : 0;
 #define ACT_DISPATCH(NT_)                \
   do {                                   \
     if (act == 0) ACT_LAUNCH(0, NT_);    \
     else if (act == 1) ACT_LAUNCH(1, NT_); \
+    else if (act == 3) ACT_LAUNCH(3, NT_); \
+    else if (act == 4) ACT_LAUNCH(4, NT_); \
     else ACT_LAUNCH(2, NT_);             \
   } while (0)
   if (mask == 3) ACT_DISPATCH(3);
@@ -889,13 +907,22 @@ int unet_bn_act_bf16(const uint16_t *z, int z_ld, uint16_t *y, int y_ld, const f
 int unet_bn_act_backward_bf16(const uint16_t *dy1, int ld1, const uint16_t *dy2, int ld2, const uint16_t *z, int z_ld,
                               const float *coef, const float *gamma_beta, uint16_t *dz, int dz_ld, float *grad_gb,
                               float *grad_bias, int C, int CoP, int64_t pixels, int act, unet_stream_t s) {
+  UNET_REQUIRE(act >= 0 && act <= 2, "unet_bn_act_backward_bf16: act must be 0 (ReLU), 1 (sigmoid) or 2 (identity)");
+  return unet_bn_act_backward_ex_bf16(dy1, ld1, dy2, ld2, z, z_ld, coef, gamma_beta, dz, dz_ld, grad_gb, grad_bias, C, CoP,
+                                      pixels, act, 0.f, s);
+}
+
+int unet_bn_act_backward_ex_bf16(const uint16_t *dy1, int ld1, const uint16_t *dy2, int ld2, const uint16_t *z, int z_ld,
+                                 const float *coef, const float *gamma_beta, uint16_t *dz, int dz_ld, float *grad_gb,
+                                 float *grad_bias, int C, int CoP, int64_t pixels, int act, float act_param,
+                                 unet_stream_t s) {
   int rc = check_view("unet_bn_act_backward_bf16 (dy1)", dy1, ld1, CoP);
   if (!rc && dy2) rc = check_view("unet_bn_act_backward_bf16 (dy2)", dy2, ld2, CoP);
   if (!rc) rc = check_view("unet_bn_act_backward_bf16 (z)", z, z_ld, CoP);
   if (!rc) rc = check_view("unet_bn_act_backward_bf16 (dz)", dz, dz_ld, CoP);
   if (rc) return rc;
   UNET_REQUIRE(coef && gamma_beta && grad_gb && C > 0 && CoP >= C && CoP % 8 == 0 && CoP <= 2048 && pixels > 0 &&
-                   act >= 0 && act <= 2,
+                   act >= 0 && act <= 4,
                "unet_bn_act_backward_bf16: bad argument (CoP must be a multiple of 8, at most 2048)");
   const RedPlan pl = plan_reduce(CoP, pixels);
   // workspace: cross-rank sums [CoP][2] double | partials [blocks][CoP][2] | ChanBwd [CoP] | bias partials [blocks][CoP]
@@ -917,7 +944,7 @@ int unet_bn_act_backward_bf16(const uint16_t *dy1, int ld1, const uint16_t *dy2,
     {                                                                                                               \
       ProfScope prof(PROF_BN_BWD_REDUCE_BF16, 0, 2.0 * elems * (dy2 ? 3.0 : 2.0), as_stream(s));                    \
       hipLaunchKernelGGL(bn_bwd_reduce_kernel<ACT_>, dim3(pl.blocks), dim3(256), lds1, as_stream(s), dy1, ld1,     \
-                         dy2, ld2, z, z_ld, cf, pl.CG, pl.PL, (i64)pixels, pl.ppb, partial, CoP);                   \
+                         dy2, ld2, z, z_ld, cf, pl.CG, pl.PL, (i64)pixels, pl.ppb, partial, CoP, act_param);        \
     }                                                                                                               \
     UNET_LAUNCH_CHECK("bn_bwd_reduce_kernel");                                                                      \
     rc = launch_finalize_bwd(partial, pl.blocks, C, CoP, (i64)pixels, gamma_beta, cf, grad_gb, cb, sync_ws,        \
@@ -928,24 +955,26 @@ int unet_bn_act_backward_bf16(const uint16_t *dy1, int ld1, const uint16_t *dy2,
       if (grad_bias)                                                                                               \
         hipLaunchKernelGGL((bn_bwd_apply_kernel<ACT_, true, 0>), dim3(pl.blocks), dim3(256), lds2, as_stream(s), \
                            dy1, ld1, dy2, ld2, z, z_ld, cf, (const ChanBwd *)cb, dz, dz_ld, pl.CG, pl.PL,          \
-                           (i64)pixels, pl.ppb, bias_part, CoP);                                                    \
+                           (i64)pixels, pl.ppb, bias_part, CoP, act_param);                                         \
       else if (nt == 3)                                                                                             \
         hipLaunchKernelGGL((bn_bwd_apply_kernel<ACT_, false, 3>), dim3(ps.blocks), dim3(256), 0, as_stream(s),      \
                            dy1, ld1, dy2, ld2, z, z_ld, cf, (const ChanBwd *)cb, dz, dz_ld, ps.CG, ps.PL,          \
-                           (i64)pixels, ps.ppb, (float *)nullptr, CoP);                                             \
+                           (i64)pixels, ps.ppb, (float *)nullptr, CoP, act_param);                                  \
       else if (nt == 1)                                                                                             \
         hipLaunchKernelGGL((bn_bwd_apply_kernel<ACT_, false, 1>), dim3(ps.blocks), dim3(256), 0, as_stream(s),      \
                            dy1, ld1, dy2, ld2, z, z_ld, cf, (const ChanBwd *)cb, dz, dz_ld, ps.CG, ps.PL,          \
-                           (i64)pixels, ps.ppb, (float *)nullptr, CoP);                                             \
+                           (i64)pixels, ps.ppb, (float *)nullptr, CoP, act_param);                                  \
       else                                                                                                          \
         hipLaunchKernelGGL((bn_bwd_apply_kernel<ACT_, false, 0>), dim3(ps.blocks), dim3(256), 0, as_stream(s),      \
                            dy1, ld1, dy2, ld2, z, z_ld, cf, (const ChanBwd *)cb, dz, dz_ld, ps.CG, ps.PL,          \
-                           (i64)pixels, ps.ppb, (float *)nullptr, CoP);                                             \
+                           (i64)pixels, ps.ppb, (float *)nullptr, CoP, act_param);                                  \
     }                                                                                                               \
     UNET_LAUNCH_CHECK("bn_bwd_apply_kernel");                                                                       \
   } while (0)
   if (act == 0) BWD_LAUNCH(0);
   else if (act == 1) BWD_LAUNCH(1);
+  else if (act == 3) BWD_LAUNCH(3);
+  else if (act == 4) BWD_LAUNCH(4);
   else BWD_LAUNCH(2);
 #undef BWD_LAUNCH
   if (grad_bias) {
@@ -1063,19 +1092,19 @@ int unet_bn_act_backward_from_partials_bf16(const uint16_t *dy, int dy_ld, const
     if (grad_bias)
       hipLaunchKernelGGL((bn_bwd_apply_kernel<0, true, 0>), dim3(pl.blocks), dim3(256),
                          sizeof(float) * (size_t)pl.PL * pl.CG * 8, as_stream(s), dy, dy_ld, (const bf16_t *)nullptr, 0, z,
-                         z_ld, cf, (const ChanBwd *)cb, dz, dz_ld, pl.CG, pl.PL, (i64)pixels, pl.ppb, bias_part, CoP);
+                         z_ld, cf, (const ChanBwd *)cb, dz, dz_ld, pl.CG, pl.PL, (i64)pixels, pl.ppb, bias_part, CoP, 0.f);
     else if (nt == 3)
       hipLaunchKernelGGL((bn_bwd_apply_kernel<0, false, 3>), dim3(ps.blocks), dim3(256), 0, as_stream(s), dy, dy_ld,
                          (const bf16_t *)nullptr, 0, z, z_ld, cf, (const ChanBwd *)cb, dz, dz_ld, ps.CG, ps.PL,
-                         (i64)pixels, ps.ppb, (float *)nullptr, CoP);
+                         (i64)pixels, ps.ppb, (float *)nullptr, CoP, 0.f);
     else if (nt == 1)
       hipLaunchKernelGGL((bn_bwd_apply_kernel<0, false, 1>), dim3(ps.blocks), dim3(256), 0, as_stream(s), dy, dy_ld,
                          (const bf16_t *)nullptr, 0, z, z_ld, cf, (const ChanBwd *)cb, dz, dz_ld, ps.CG, ps.PL,
-                         (i64)pixels, ps.ppb, (float *)nullptr, CoP);
+                         (i64)pixels, ps.ppb, (float *)nullptr, CoP, 0.f);
     else
       hipLaunchKernelGGL((bn_bwd_apply_kernel<0, false, 0>), dim3(ps.blocks), dim3(256), 0, as_stream(s), dy, dy_ld,
                          (const bf16_t *)nullptr, 0, z, z_ld, cf, (const ChanBwd *)cb, dz, dz_ld, ps.CG, ps.PL,
-                         (i64)pixels, ps.ppb, (float *)nullptr, CoP);
+                         (i64)pixels, ps.ppb, (float *)nullptr, CoP, 0.f);
   }
   UNET_LAUNCH_CHECK("bn_bwd_apply_kernel");
   if (grad_bias) {

@@ -927,6 +927,15 @@ class Net {
     if (n.activation == NONE && none_is_identity_) return NONE;
     return ReLU;
   }
+  // the same as the activation code of the fused bf16 batch-norm kernels: 0 ReLU, 1 sigmoid, 3 leaky ReLU, 4 tanh
+  int act_code(const Node &n) const {
+    switch (effective_activation(n)) {
+      case SIGMOID: return 1;
+      case LEAKY_ReLU: return 3;
+      case TANH: return 4;
+      default: return 0;
+    }
+  }
   void apply_activation(Node &n, int64_t out_n) {  // n.bn -> n.act
     switch (effective_activation(n)) {
       case SIGMOID: UNET_CALL(unet_sigmoid_f32(n.bn.f32(), n.act.f32(), out_n, stream_)); break;
@@ -1181,8 +1190,6 @@ class Net {
       switch (n.type) {
         case CONV_LAYER:
           if (n.kernel != 3 || n.padding != 1 || n.stride != 1) return why = "a convolution that is not 3x3/pad 1/stride 1", false;
-          if ((n.activation == TANH || n.activation == LEAKY_ReLU) && !(is_final && (n.out_c % 32 != 0 || loss_ == LossFunction::kCrossEntropyLoss)))
-            return why = "a hidden layer with an activation other than ReLU / sigmoid", false;
           if (n.parents.empty() ? n.in_c > 32 : n.in_c % 32 != 0) return why = "a convolution whose C_in is not a multiple of 32", false;
           if (n.out_c % 32 != 0) {
             if (!is_final || n.out_c > 32) return why = "a hidden convolution whose C_out is not a multiple of 32", false;
@@ -1224,7 +1231,7 @@ class Net {
     for (size_t i = 0; i < nodes_.size(); ++i) {
       if (nodes_[i].type != MAX_POOL_LAYER) continue;
       Node &p = nodes_[nodes_[i].parents[0]];
-      if (p.has_params() && !p.narrow && p.pool_child < 0) p.pool_child = (int)i;
+      if (p.has_params() && !p.narrow && p.pool_child < 0 && act_code(p) <= 1) p.pool_child = (int)i;  // (the pooled kernels know ReLU and sigmoid)
     }
     return true;
   }
@@ -1342,7 +1349,7 @@ class Net {
         const float *gb = w + n.num_wb;
         float *parts = (inference || n.narrow) ? nullptr : n.stat_partials.f32();
         int num_parts;
-        const bool fold_bn = inference && !n.narrow && !(n.type == CONV_LAYER && n.activation == SIGMOID);
+        const bool fold_bn = inference && !n.narrow && act_code(n) == 0;
         if (fold_bn) {
           // inference: BN (running statistics) + ReLU folded into the conv epilogue, straight into y
           if (n.type == CONV_LAYER)
@@ -1384,7 +1391,7 @@ class Net {
           UNET_CALL(unet_bn_finalize_bf16(parts, num_parts, n.out_c, n.cop, out_pix, gb, n.batch_stats.f32(),
                                           n.running.f32(), n.coef.f32(), stream_));
         const float *coef = inference ? n.coef_inf.f32() : n.coef.f32();
-        const int act = (n.type == CONV_LAYER && n.activation == SIGMOID) ? 1 : 0;
+        const int act = act_code(n);
         if (n.pool_child >= 0) {
           // the skip layers of the encoder: activation, pooled activation and tie mask from one pass over z
           Node &q = nodes_[n.pool_child];
@@ -1393,7 +1400,7 @@ class Net {
           q.pooled_by_parent = true;
           break;
         }
-        UNET_CALL(unet_bn_act_bf16(n.zb.u16(), n.cop, n.y_ptr, n.y_ld, coef, n.cop, out_pix, act, stream_));
+        UNET_CALL(unet_bn_act_ex_bf16(n.zb.u16(), n.cop, n.y_ptr, n.y_ld, coef, n.cop, out_pix, act, n.leaky, stream_));
         break;
       }
       case MAX_POOL_LAYER: {
@@ -1427,7 +1434,7 @@ class Net {
   bool concat_second_is_fusable(const Node &c) const {
     const Node &u = nodes_[c.parents[1]];
     return u.has_params() && !u.narrow && u.num_children == 1 && c.num_children == 1 && c.c1 % 64 == 0 &&
-           c.cop % 64 == 0 && u.cop == c.c2 && !(u.type == CONV_LAYER && u.activation == SIGMOID);
+           c.cop % 64 == 0 && u.cop == c.c2 && act_code(u) == 0;
   }
 
   // The gradient of a convolution bias that feeds a batch norm is identically zero: dz, the batch-norm
@@ -1458,7 +1465,7 @@ class Net {
             // one output channel: data and weight gradients straight from the fp32 dz, on the head kernels
             Node &p = nodes_[n.parents[0]];
             const bool fuse = p.has_params() && !p.narrow && p.num_children == 1 && p.concat_child < 0 && !p.g_written &&
-                              !(p.type == CONV_LAYER && p.activation == SIGMOID);
+                              act_code(p) == 0;
             UNET_CALL(unet_conv3x3_head_dgrad_bf16(g1, w, n.in_c, p.gb.u16(), p.cop, fuse ? p.zb.u16() : nullptr, p.cop,
                                                    fuse ? p.coef.f32() : nullptr, fuse ? p.bwd_partials.f32() : nullptr,
                                                    batch, n.in_h, n.in_w, n.cip, (!fuse && p.g_written) ? 1 : 0, stream_));
@@ -1486,7 +1493,7 @@ class Net {
           const int l1 = n.g_written ? n.cop : n.g2_ld;
           const uint16_t *d2 = (n.g_written && n.g2_ptr) ? n.g2_ptr : nullptr;
           if (!d1 && !n.pool_src) return;  // not on a path to the loss
-          const int act = (n.type == CONV_LAYER && n.activation == SIGMOID) ? 1 : 0;
+          const int act = act_code(n);
           if (n.pool_src) {
             // a skip layer: the gradient through the max pool is gathered from the pooled gradient and the tie
             // mask inside the batch-norm backward passes, next to the concat slice d1 (if any)
@@ -1501,9 +1508,9 @@ class Net {
                                                               gw + n.num_wb, kNoBiasGrad, n.out_c, n.cop, out_pix,
                                                               stream_));
           else
-            UNET_CALL(unet_bn_act_backward_bf16(d1, l1, d2, n.g2_ld, n.zb.u16(), n.cop, n.coef.f32(), w + n.num_wb, dz,
-                                                n.cop, gw + n.num_wb, kNoBiasGrad, n.out_c, n.cop, out_pix, act,
-                                                stream_));
+            UNET_CALL(unet_bn_act_backward_ex_bf16(d1, l1, d2, n.g2_ld, n.zb.u16(), n.cop, n.coef.f32(), w + n.num_wb, dz,
+                                                   n.cop, gw + n.num_wb, kNoBiasGrad, n.out_c, n.cop, out_pix, act,
+                                                   n.leaky, stream_));
           (void)gbias;
         }
         const uint16_t *x = n.parents.empty() ? x16_.u16() : nodes_[n.parents[0]].y_ptr;
@@ -1514,7 +1521,7 @@ class Net {
           // BN + ReLU layer, the data-gradient kernel also does the pixel reduction of the parent's
           // batch-norm backward.
           const bool fuse = p.has_params() && !p.narrow && p.num_children == 1 && p.concat_child < 0 && !p.g_written &&
-                            !(p.type == CONV_LAYER && p.activation == SIGMOID);
+                            act_code(p) == 0;
           if (fuse) {
             if (n.type == CONV_LAYER)
               UNET_CALL(unet_conv3x3_dgrad_bnred_bf16(dz, n.cop, n.w_bwd.u16(), p.gb.u16(), p.cop, p.zb.u16(), p.cop,
@@ -1554,8 +1561,8 @@ class Net {
       case MAX_POOL_LAYER: {
         if (!n.g_written) return;
         Node &p = nodes_[n.parents[0]];
-        if (p.has_params() && !p.narrow && !p.pool_src) {
-          p.pool_src = &n;  // gathered by the parent's batch-norm backward
+        if (p.has_params() && !p.narrow && !p.pool_src && act_code(p) <= 1) {
+          p.pool_src = &n;  // gathered by the parent's batch-norm backward (ReLU and sigmoid layers)
           break;
         }
         UNET_CALL(unet_max_pool2x2_backward_bf16(n.gb.u16(), n.cop, n.mask.u8(), p.gb.u16(), p.cop, batch, n.in_h, n.in_w,
