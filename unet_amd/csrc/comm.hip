@@ -9,6 +9,7 @@
 // not pay for (or depend on) it, and a process that already holds an RCCL (e.g. through torch) shares that
 // copy, because the loader resolves by soname.
 #include <dlfcn.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <rccl/rccl.h>
@@ -98,6 +99,40 @@ int reserve_stage(Comm *c, size_t elems) {
   return UNET_OK;
 }
 
+// ---- laboratory: what the collective's resident kernels cost the kernels they overlap --------------------------
+// UNET_LAB_COMM_EMULATE="<workgroups>,<LDS bytes>,<GB/s>": on a ONE-rank communicator (a one-GPU box), the bucket
+// all-reduce of unet_allreduce_begin is replaced by a kernel that holds that many workgroup slots (256 threads and
+// that much LDS each, no memory traffic) for the time the bucket would take at that rate -- a stand-in for RCCL's
+// device kernels on an 8-GPU node, issued from the same place, on the same stream, behind the same event.  Used
+// by tools/lab_comm_overlap.py; never active unless the variable is set.
+struct CommEmulation {
+  int wgs = 0, lds = 0;
+  double gbps = 0;
+};
+const CommEmulation &comm_emulation() {
+  static const CommEmulation e = [] {
+    CommEmulation v;
+    if (const char *t = getenv("UNET_LAB_COMM_EMULATE")) {
+      if (sscanf(t, "%d,%d,%lf", &v.wgs, &v.lds, &v.gbps) != 3 || v.wgs < 1 || v.wgs > 256 || v.lds < 0 || v.lds > 65536 ||
+          v.gbps <= 0)
+        v = CommEmulation();
+    }
+    return v;
+  }();
+  return e;
+}
+__global__ __launch_bounds__(256) void occupy_slots_kernel(long long ticks) {  // ticks of the 100 MHz wall clock
+  extern __shared__ unsigned char held[];
+  const long long t0 = wall_clock64();
+  int spins = 0;
+  // a time limit and a trip limit: every wave leaves
+  while (wall_clock64() - t0 < ticks && spins < (1 << 22)) {
+    __builtin_amdgcn_s_sleep(32);
+    ++spins;
+  }
+  if (spins < 0) held[threadIdx.x] = 0;
+}
+
 // The communicator batch-norm launchers synchronise their statistics over (NULL = per-rank statistics).
 Comm *g_bn_sync = nullptr;
 
@@ -185,6 +220,16 @@ int unet_allreduce_begin(unet_comm_t comm, float *data, int64_t count, unet_even
   Comm *c = static_cast<Comm *>(comm);
   UNET_REQUIRE(c && data && count > 0, "unet_allreduce_begin: bad argument");
   if (ready) UNET_HIP_TRY(hipStreamWaitEvent(c->stream, (hipEvent_t)ready, 0));
+  const CommEmulation &emu = comm_emulation();
+  if (emu.wgs > 0 && c->world == 1) {
+    const double bytes = (double)count * (c->bf16_gradients ? 2.0 : 4.0);
+    long long ticks = (long long)(bytes / (emu.gbps * 1e9) * 1e8);
+    if (ticks > 100000000ll) ticks = 100000000ll;  // one second at most
+    hipLaunchKernelGGL(occupy_slots_kernel, dim3(emu.wgs), dim3(256), emu.lds, c->stream, ticks);
+    UNET_LAUNCH_CHECK("occupy_slots_kernel");
+    c->pending = true;
+    return UNET_OK;
+  }
   if (c->bf16_gradients) {
     // half the bytes on the links and half the time the collective's kernels stay resident: the bucket is
     // rounded to bf16, averaged in bf16 and widened again, all on the communication stream
