@@ -5,13 +5,18 @@
 
 Per kernel name (template instances kept apart), launch-weighted means of:
   us          dispatch duration (End - Start timestamps of the counter pass: a profiled pass, slower than a bare run)
-  clk GHz     GRBM_GUI_ACTIVE / 8 XCDs / duration: the clock the chip held during the kernel
-  MFMA busy   SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x 256 CUs x kernel cycles): share of matrix-core cycles in use
-  MFMA/peak   the bf16 rate that share gives at the held clock, over the 2.5 PFLOP/s nominal peak (2.4 GHz)
-  issue       SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES: share of wave-cycles in which the wave issues something
-  wait        SQ_WAIT_ANY / SQ_WAVE_CYCLES (parked on s_waitcnt or a barrier), stall = SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES
-  LDS busy    SQ_LDS_IDX_ACTIVE / (256 CUs x kernel cycles); conflict = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE
-  LDS stall   SQ_WAIT_INST_LDS / SQ_WAVE_CYCLES
+  clk GHz     SQ_BUSY_CU_CYCLES / 256 CUs / duration: the clock the chip held, for kernels that keep every CU busy
+              from start to end (the persistent convolution kernels; it reads low for kernels that do not).
+              GRBM_GUI_ACTIVE / 8 / duration is printed beside it: it counts activity around the dispatch as well
+              and reads 10-20 % high on dispatches of under 0.1 ms.
+  MFMA busy   SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x SQ_BUSY_CU_CYCLES): share of the busy CUs' matrix-core cycles in
+              use (the counter adds 16 per v_mfma_f32_16x16x32_bf16, 32 per 32x32x16: checked against SQ_INSTS_MFMA)
+  MFMA/peak   that share at the held clock over the nominal 2.4 GHz: what fraction of the 2.5 PFLOP/s figure the
+              kernel's issued MFMAs amount to (padded channels included)
+  issue / wait / stall   SQ_ACTIVE_INST_ANY, SQ_WAIT_ANY (parked on s_waitcnt or a barrier), SQ_WAIT_INST_ANY (an
+              instruction waiting to issue) over SQ_WAVE_CYCLES
+  LDS busy    SQ_LDS_IDX_ACTIVE / SQ_BUSY_CU_CYCLES (4 per ds_read_b128: checked against SQ_INSTS_LDS);
+              conflict = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE; LDS stall = SQ_WAIT_INST_LDS / SQ_WAVE_CYCLES
 rocprofv3 reports each counter summed over the device (all XCDs, SEs, CUs).
 """
 import collections
@@ -52,7 +57,7 @@ def main():
         cyc = m.get("GRBM_GUI_ACTIVE", 0.0) / XCDS
         rows.append((us * n, k, n, us, cyc, m))
     rows.sort(reverse=True)
-    print("| kernel | launches | us | clk GHz | MFMA busy | MFMA/peak | issue | wait | stall | LDS busy | conflict | LDS stall |")
+    print("| kernel | launches | us | clk GHz (CU-busy / GRBM) | MFMA busy | MFMA/peak | issue | wait | stall | LDS busy | conflict | LDS stall |")
     print("|---|---|---|---|---|---|---|---|---|---|---|---|")
 
     def pct(x):
@@ -60,17 +65,20 @@ def main():
 
     for _, k, n, us, cyc, m in rows[:40]:
         wc = m.get("SQ_WAVE_CYCLES")
-        clk = cyc / (us * 1e3) if cyc and us else None
-        busy = m["SQ_VALU_MFMA_BUSY_CYCLES"] / (SIMDS * CUS * cyc) if cyc and "SQ_VALU_MFMA_BUSY_CYCLES" in m else None
+        cu = m.get("SQ_BUSY_CU_CYCLES")
+        clk = cu / CUS / (us * 1e3) if cu and us else None
+        clk_grbm = cyc / (us * 1e3) if cyc and us else None
+        busy = m["SQ_VALU_MFMA_BUSY_CYCLES"] / (SIMDS * cu) if cu and "SQ_VALU_MFMA_BUSY_CYCLES" in m else None
         frac = busy * clk / 2.4 if busy is not None and clk else None
         issue = m["SQ_ACTIVE_INST_ANY"] / wc if wc and "SQ_ACTIVE_INST_ANY" in m else None
         wait = m["SQ_WAIT_ANY"] / wc if wc and "SQ_WAIT_ANY" in m else None
         stall = m["SQ_WAIT_INST_ANY"] / wc if wc and "SQ_WAIT_INST_ANY" in m else None
-        lds = m["SQ_LDS_IDX_ACTIVE"] / (CUS * cyc) if cyc and "SQ_LDS_IDX_ACTIVE" in m else None
+        lds = m["SQ_LDS_IDX_ACTIVE"] / cu if cu and "SQ_LDS_IDX_ACTIVE" in m else None
         conf = m["SQ_LDS_BANK_CONFLICT"] / m["SQ_LDS_IDX_ACTIVE"] if m.get("SQ_LDS_IDX_ACTIVE") and "SQ_LDS_BANK_CONFLICT" in m else None
         ldsst = m["SQ_WAIT_INST_LDS"] / wc if wc and "SQ_WAIT_INST_LDS" in m else None
-        print(f"| `{k}` | {n} | {us:.1f} | {clk:.2f} | {pct(busy)} | {pct(frac)} | {pct(issue)} | {pct(wait)} | {pct(stall)} | "
-              f"{pct(lds)} | {pct(conf)} | {pct(ldsst)} |" if clk else f"| `{k}` | {n} | {us:.1f} | - | - | - | {pct(issue)} | {pct(wait)} | {pct(stall)} | - | {pct(conf)} | {pct(ldsst)} |")
+        clks = "-" if clk is None else f"{clk:.2f} / {clk_grbm:.2f}" if clk_grbm else f"{clk:.2f}"
+        print(f"| `{k}` | {n} | {us:.1f} | {clks} | {pct(busy)} | {pct(frac)} | {pct(issue)} | {pct(wait)} | {pct(stall)} | "
+              f"{pct(lds)} | {pct(conf)} | {pct(ldsst)} |")
 
 
 if __name__ == "__main__":
