@@ -74,7 +74,7 @@ def table():
     for wgs in (16, 64):
         for gbps in (100, 200):
             rows.append((f"{wgs},37664,{gbps}", False))
-    rows += [("64,37664,100", True), ("64,37664,18", False), ("none", False)]   # 18 GB/s: the slots stay held for about a whole step
+    rows += [("64,37664,100", True), ("none", False)]
     base = None
     for spec, bf16 in rows:
         cmd = [sys.executable, os.path.abspath(__file__), "--one", spec] + (["--bf16"] if bf16 else [])
