@@ -144,6 +144,11 @@ int unet_convolve_backward_f32(const float *grad_activations, const float *input
 int unet_batch_norm_train_f32(const float *inputs, float *activations, const float *weights,
                               float *BN_batch_stats, float *BN_running_stats, int num_channels,
                               int H, int W, int batch_size, unet_stream_t stream);
+/* cudaBatchNormTrain followed by cudaRelu (convolution_layer_functions.h:42-65) in one pass over the tensor:
+ * activations = max(0, batch norm), the same values bit for bit; the pre-activation tensor is not written. */
+int unet_batch_norm_train_relu_f32(const float *inputs, float *activations, const float *weights,
+                                   float *BN_batch_stats, float *BN_running_stats, int num_channels,
+                                   int H, int W, int batch_size, unet_stream_t stream);
 /* unet_batch_norm_train_f32 for callers that cannot allocate device memory (code under HIP graph capture,
  * tight serving loops, harnesses that forbid hipMalloc).  It has no counterpart in the reference.  Same
  * arguments and results; the per-slice partial sums go to a fixed 1 MiB array inside the library's device
@@ -178,6 +183,13 @@ int unet_batch_norm_backward_f32(const float *grad_activations, const float *inp
                                  const float *BN_batch_stats, const float *weights,
                                  float *grad_inputs, float *grad_weights, int num_channels,
                                  int H, int W, int batch_size, unet_stream_t stream);
+/* cudaReluBackward followed by cudaBatchNormBackward (convolution_layer_functions.h:92-113) without the
+ * intermediate tensor: grad_activations is the gradient behind the ReLU, activations that ReLU's OUTPUT (its
+ * sign is the pre-activation's); same results bit for bit as the two calls. */
+int unet_batch_norm_relu_backward_f32(const float *grad_activations, const float *activations, const float *inputs,
+                                      const float *BN_batch_stats, const float *weights, float *grad_inputs,
+                                      float *grad_weights, int num_channels, int H, int W, int batch_size,
+                                      unet_stream_t stream);
 
 /* ---- activations (cuda_lib.h:90-98, 151-161) ---------------------------- */
 

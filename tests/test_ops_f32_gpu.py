@@ -364,6 +364,34 @@ def test_difference_and_xent(G, capi, oracle, golden):
     assert_close(G.host(gl), g_ref, what="cross entropy grad vs oracle")
 
 
+def test_batch_norm_fused_with_relu_is_bit_identical_to_the_two_calls(G, capi):
+    """unet_batch_norm_train_relu_f32 = cudaBatchNormTrain + cudaRelu, unet_batch_norm_relu_backward_f32 =
+    cudaReluBackward + cudaBatchNormBackward: the same bits, one tensor pass fewer each way."""
+    rng = np.random.default_rng(31)
+    n, c, h, w = 3, 5, 17, 23
+    x = rng.standard_normal((n, c, h, w)).astype(np.float32)
+    gb = (rng.standard_normal(2 * c) * 0.5 + np.tile([1.0, 0.0], c)).astype(np.float32)
+    dy = rng.standard_normal((n, c, h, w)).astype(np.float32)
+    xd, gbd, dyd = G.dev(x), G.dev(gb), G.dev(dy)
+    bn, y2, y1 = G.empty(x.shape), G.empty(x.shape), G.empty(x.shape)
+    st2, st1 = G.empty((2 * c,)), G.empty((2 * c,))
+    run2, run1 = G.dev(np.tile([0.0, 1.0], c).astype(np.float32)), G.dev(np.tile([0.0, 1.0], c).astype(np.float32))
+    capi.unet_batch_norm_train_f32(G.p(xd), G.p(bn), G.p(gbd), G.p(st2), G.p(run2), c, h, w, n, None)
+    capi.unet_relu_f32(G.p(bn), G.p(y2), x.size, None)
+    capi.unet_batch_norm_train_relu_f32(G.p(xd), G.p(y1), G.p(gbd), G.p(st1), G.p(run1), c, h, w, n, None)
+    assert_exact(G.host(y1), G.host(y2))
+    assert_exact(G.host(st1), G.host(st2))
+    assert_exact(G.host(run1), G.host(run2))
+    g2, dx2, dx1 = G.empty(x.shape), G.empty(x.shape), G.empty(x.shape)
+    gg2, gg1 = G.empty((2 * c,)), G.empty((2 * c,))
+    capi.unet_relu_backward_f32(G.p(dyd), G.p(bn), G.p(g2), x.size, None)
+    capi.unet_batch_norm_backward_f32(G.p(g2), G.p(xd), G.p(st2), G.p(gbd), G.p(dx2), G.p(gg2), c, h, w, n, None)
+    capi.unet_batch_norm_relu_backward_f32(G.p(dyd), G.p(y1), G.p(xd), G.p(st1), G.p(gbd), G.p(dx1), G.p(gg1), c, h, w, n,
+                                           None)
+    assert_exact(G.host(dx1), G.host(dx2))
+    assert_exact(G.host(gg1), G.host(gg2))
+
+
 def test_cross_entropy_ignores_labels_that_are_no_class(G, capi, oracle):
     """Ignore labels (255, -1, anything outside [0, C)) must not index the logits: such pixels add no loss, get
     a zero gradient and leave the mean (torch's ignore_index, for every value that is not a class)."""

@@ -250,12 +250,14 @@ __global__ __launch_bounds__(256) void nonfinite_flag_kernel(const float *__rest
 // ---- batch norm ---------------------------------------------------------------
 // Channel c's elements are the N planes x[(n*C+c)*HW .. +HW).  A block reduces
 // slice `s` of the flattened (n, i) range; partial[(c*S+s)*2 + {0,1}].
-template <int MODE>  // 0: (sum x, sum x^2)   1: (sum dy*xhat, sum dy)
+// RELU (MODE 1): dy is the gradient behind a ReLU whose output is ymask: dy counts where ymask > 0.
+template <int MODE, bool RELU = false>  // 0: (sum x, sum x^2)   1: (sum dy*xhat, sum dy)
 __global__ __launch_bounds__(256) void bn_partial_kernel(const float *__restrict__ x,
                                                          const float *__restrict__ dy,
                                                          const float *__restrict__ stats,
                                                          float *__restrict__ partial, int C, i64 HW,
-                                                         i64 M, int S, float Mstat) {
+                                                         i64 M, int S, float Mstat,
+                                                         const float *__restrict__ ymask = nullptr) {
   __shared__ float red[2 * 4];
   const int c = blockIdx.y, s = blockIdx.x;
   const i64 chunk = (M + S - 1) / S;
@@ -285,6 +287,7 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float *__restrict
       const i64 idx = (n * C + c) * HW + i;
       v[u] = x[idx];
       g[u] = MODE == 1 ? dy[idx] : 0.f;
+      if (MODE == 1 && RELU) g[u] = ymask[idx] > 0.f ? g[u] : 0.f;
       i += blockDim.x;
     }
 #pragma unroll
@@ -309,7 +312,8 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float *__restrict
       acc[0] += v;
       acc[1] += v * v;
     } else {
-      const float g = dy[idx];
+      float g = dy[idx];
+      if (RELU) g = ymask[idx] > 0.f ? g : 0.f;
       acc[0] += g * ((v - mean) * inv);
       acc[1] += g;
     }
@@ -389,14 +393,16 @@ __global__ __launch_bounds__(64) void bn_publish_kernel(const double *__restrict
 // MODE 1: inference (eps inside sqrt, stats = [mean,var])
 // MODE 2: backward dx (stats = raw sums, gw = [dgamma,dbeta])
 // MODE 3: MODE 1 followed by ReLU (the same two roundings as the two passes, one pass over the tensor)
-template <int MODE>
+// RELU: MODE 0 followed by ReLU likewise; MODE 2 with dy masked by the ReLU's output ymask (ReLU backward folded in)
+template <int MODE, bool RELU = false>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float *__restrict__ x,
                                                        const float *__restrict__ dy,
                                                        float *__restrict__ out,
                                                        const float *__restrict__ gb,
                                                        const float *__restrict__ stats,
                                                        const float *__restrict__ gw, int C, i64 HW,
-                                                       i64 planes, float M) {
+                                                       i64 planes, float M,
+                                                       const float *__restrict__ ymask = nullptr) {
   // grid.y strides over planes (n*C + c); grid.x over the plane
   for (i64 p = blockIdx.y; p < planes; p += gridDim.y) {
     const int c = (int)(p % C);
@@ -424,13 +430,16 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float *__restrict__
     const float *xp = x + p * HW;
     float *op = out + p * HW;
     const float *gp = (MODE == 2) ? dy + p * HW : nullptr;
+    const float *mp = (MODE == 2 && RELU) ? ymask + p * HW : nullptr;
     for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < HW; i += (i64)gridDim.x * blockDim.x) {
       if (MODE == 2) {
         const float xh = (xp[i] - mean) * inv;
-        op[i] = a * (gp[i] - k1 - xh * k2);
+        float g = gp[i];
+        if (RELU) g = mp[i] > 0.f ? g : 0.f;
+        op[i] = a * (g - k1 - xh * k2);
       } else {
         const float y = MODE == 0 ? gamma * ((xp[i] - mean) * inv) + gb[2 * c + 1] : a * xp[i] + b;
-        op[i] = (MODE == 3) ? (y > 0.f ? y : 0.f) : y;
+        op[i] = (MODE == 3 || (MODE == 0 && RELU)) ? (y > 0.f ? y : 0.f) : y;
       }
     }
   }
@@ -850,7 +859,7 @@ static dim3 bn_apply_grid(i64 HW, i64 planes) {
 // (unet_bn_set_sync): the channel sums are then added over all ranks and M counts all ranks' elements.
 static int bn_train_launch(const float *inputs, float *activations, const float *weights, float *BN_batch_stats,
                            float *BN_running_stats, int C, i64 HW, int N, int S, float *partials, double *sync_sums,
-                           unet_stream_t s) {
+                           unet_stream_t s, bool relu = false) {
   const i64 M = HW * N;
   float Mg = (float)M;
   hipLaunchKernelGGL(bn_partial_kernel<0>, dim3(S, C), dim3(256), 0, as_stream(s), inputs,
@@ -872,19 +881,24 @@ static int bn_train_launch(const float *inputs, float *activations, const float 
                        BN_batch_stats, BN_running_stats, C, S, Mg);
     UNET_LAUNCH_CHECK("bn_finalize_kernel");
   }
-  hipLaunchKernelGGL(bn_apply_kernel<0>, bn_apply_grid(HW, (i64)N * C), dim3(256), 0, as_stream(s), inputs,
-                     (const float *)nullptr, activations, weights, (const float *)BN_batch_stats,
-                     (const float *)nullptr, C, HW, (i64)N * C, Mg);
+  if (relu)
+    hipLaunchKernelGGL((bn_apply_kernel<0, true>), bn_apply_grid(HW, (i64)N * C), dim3(256), 0, as_stream(s), inputs,
+                       (const float *)nullptr, activations, weights, (const float *)BN_batch_stats,
+                       (const float *)nullptr, C, HW, (i64)N * C, Mg, (const float *)nullptr);
+  else
+    hipLaunchKernelGGL((bn_apply_kernel<0, false>), bn_apply_grid(HW, (i64)N * C), dim3(256), 0, as_stream(s), inputs,
+                       (const float *)nullptr, activations, weights, (const float *)BN_batch_stats,
+                       (const float *)nullptr, C, HW, (i64)N * C, Mg, (const float *)nullptr);
   UNET_LAUNCH_CHECK("bn_apply_kernel<0>");
   return UNET_OK;
 }
 
-int unet_batch_norm_train_f32(const float *inputs, float *activations, const float *weights,
-                              float *BN_batch_stats, float *BN_running_stats, int C, int H, int W,
-                              int N, unet_stream_t s) {
-  int rc = bn_check("unet_batch_norm_train_f32", C, H, W, N);
+static int bn_train_impl(const char *who, const float *inputs, float *activations, const float *weights,
+                         float *BN_batch_stats, float *BN_running_stats, int C, int H, int W, int N, bool relu,
+                         unet_stream_t s) {
+  int rc = bn_check(who, C, H, W, N);
   if (rc) return rc;
-  UNET_REQUIRE(inputs && activations && weights && BN_batch_stats, "unet_batch_norm_train_f32: NULL pointer");
+  UNET_REQUIRE(inputs && activations && weights && BN_batch_stats, "%s: NULL pointer", who);
   const i64 HW = (i64)H * W, M = HW * N;
   const int S = bn_splits(M, C);
   // workspace: cross-rank sums [2C] double (synchronised statistics only) | partials [C][S][2]
@@ -893,7 +907,21 @@ int unet_batch_norm_train_f32(const float *inputs, float *activations, const flo
   rc = unet_workspace(&ws, sizeof(float) * (n_sync + 2 * (size_t)C * S), as_stream(s));
   if (rc) return rc;
   return bn_train_launch(inputs, activations, weights, BN_batch_stats, BN_running_stats, C, HW, N, S,
-                         (float *)ws + n_sync, n_sync ? (double *)ws : nullptr, s);
+                         (float *)ws + n_sync, n_sync ? (double *)ws : nullptr, s, relu);
+}
+
+int unet_batch_norm_train_f32(const float *inputs, float *activations, const float *weights,
+                              float *BN_batch_stats, float *BN_running_stats, int C, int H, int W,
+                              int N, unet_stream_t s) {
+  return bn_train_impl("unet_batch_norm_train_f32", inputs, activations, weights, BN_batch_stats, BN_running_stats, C,
+                       H, W, N, false, s);
+}
+
+int unet_batch_norm_train_relu_f32(const float *inputs, float *activations, const float *weights,
+                                   float *BN_batch_stats, float *BN_running_stats, int C, int H, int W,
+                                   int N, unet_stream_t s) {
+  return bn_train_impl("unet_batch_norm_train_relu_f32", inputs, activations, weights, BN_batch_stats,
+                       BN_running_stats, C, H, W, N, true, s);
 }
 
 // ---- batch norm training forward for callers that must not allocate --------------------------------
@@ -973,13 +1001,14 @@ int unet_batch_norm_inference_relu_f32(const float *inputs, float *activations, 
   return UNET_OK;
 }
 
-int unet_batch_norm_backward_f32(const float *grad_activations, const float *inputs,
-                                 const float *BN_batch_stats, const float *weights, float *grad_inputs,
-                                 float *grad_weights, int C, int H, int W, int N, unet_stream_t s) {
-  int rc = bn_check("unet_batch_norm_backward_f32", C, H, W, N);
+// relu_out != NULL: grad_activations is the gradient behind a ReLU with output relu_out (ReLU backward folded in)
+static int bn_backward_impl(const char *who, const float *grad_activations, const float *relu_out, const float *inputs,
+                            const float *BN_batch_stats, const float *weights, float *grad_inputs,
+                            float *grad_weights, int C, int H, int W, int N, unet_stream_t s) {
+  int rc = bn_check(who, C, H, W, N);
   if (rc) return rc;
   UNET_REQUIRE(grad_activations && inputs && BN_batch_stats && weights && grad_inputs && grad_weights,
-               "unet_batch_norm_backward_f32: NULL pointer");
+               "%s: NULL pointer", who);
   const i64 HW = (i64)H * W, M = HW * N;
   const int S = bn_splits(M, C);
   const bool sync = unet_bn_sync_on();
@@ -994,8 +1023,12 @@ int unet_batch_norm_backward_f32(const float *grad_activations, const float *inp
     if (rc) return rc;
   }
   const float Mg = (float)(M * world);
-  hipLaunchKernelGGL(bn_partial_kernel<1>, dim3(S, C), dim3(256), 0, as_stream(s), inputs, grad_activations,
-                     BN_batch_stats, partials, C, HW, M, S, Mg);
+  if (relu_out)
+    hipLaunchKernelGGL((bn_partial_kernel<1, true>), dim3(S, C), dim3(256), 0, as_stream(s), inputs, grad_activations,
+                       BN_batch_stats, partials, C, HW, M, S, Mg, relu_out);
+  else
+    hipLaunchKernelGGL((bn_partial_kernel<1, false>), dim3(S, C), dim3(256), 0, as_stream(s), inputs, grad_activations,
+                       BN_batch_stats, partials, C, HW, M, S, Mg, (const float *)nullptr);
   UNET_LAUNCH_CHECK("bn_partial_kernel<1>");
   if (sync) {
     double *sums = (double *)ws;
@@ -1012,13 +1045,33 @@ int unet_batch_norm_backward_f32(const float *grad_activations, const float *inp
                        grad_weights, (float *)nullptr, C, S, Mg);
     UNET_LAUNCH_CHECK("bn_finalize_kernel");
   }
-  hipLaunchKernelGGL(bn_apply_kernel<2>, bn_apply_grid(HW, (i64)N * C), dim3(256), 0, as_stream(s), inputs,
-                     grad_activations, grad_inputs, weights, BN_batch_stats, (const float *)grad_weights, C, HW,
-                     (i64)N * C, Mg);
+  if (relu_out)
+    hipLaunchKernelGGL((bn_apply_kernel<2, true>), bn_apply_grid(HW, (i64)N * C), dim3(256), 0, as_stream(s), inputs,
+                       grad_activations, grad_inputs, weights, BN_batch_stats, (const float *)grad_weights, C, HW,
+                       (i64)N * C, Mg, relu_out);
+  else
+    hipLaunchKernelGGL((bn_apply_kernel<2, false>), bn_apply_grid(HW, (i64)N * C), dim3(256), 0, as_stream(s), inputs,
+                       grad_activations, grad_inputs, weights, BN_batch_stats, (const float *)grad_weights, C, HW,
+                       (i64)N * C, Mg, (const float *)nullptr);
   UNET_LAUNCH_CHECK("bn_apply_kernel<2>");
   // the gradient all-reduce takes the mean over ranks: hand it this rank's share of the global sums
   if (sync && world > 1) return unet_scale_f32(grad_weights, 1.0f / (float)world, 2 * (i64)C, s);
   return UNET_OK;
+}
+
+int unet_batch_norm_backward_f32(const float *grad_activations, const float *inputs,
+                                 const float *BN_batch_stats, const float *weights, float *grad_inputs,
+                                 float *grad_weights, int C, int H, int W, int N, unet_stream_t s) {
+  return bn_backward_impl("unet_batch_norm_backward_f32", grad_activations, nullptr, inputs, BN_batch_stats, weights,
+                          grad_inputs, grad_weights, C, H, W, N, s);
+}
+
+int unet_batch_norm_relu_backward_f32(const float *grad_activations, const float *activations, const float *inputs,
+                                      const float *BN_batch_stats, const float *weights, float *grad_inputs,
+                                      float *grad_weights, int C, int H, int W, int N, unet_stream_t s) {
+  UNET_REQUIRE(activations, "unet_batch_norm_relu_backward_f32: NULL pointer");
+  return bn_backward_impl("unet_batch_norm_relu_backward_f32", grad_activations, activations, inputs, BN_batch_stats,
+                          weights, grad_inputs, grad_weights, C, H, W, N, s);
 }
 
 // ---- max pool -------------------------------------------------------------------

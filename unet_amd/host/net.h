@@ -983,6 +983,13 @@ class Net {
                                                        n.out_c, batch, stream_));
           break;
         }
+        if (!inference && effective_activation(n) == ReLU) {
+          // batch norm and ReLU in one pass; backward takes the ReLU mask from the output (the pre-activation
+          // tensor is never written)
+          UNET_CALL(unet_batch_norm_train_relu_f32(n.z.f32(), n.act.f32(), gb, n.batch_stats.f32(), n.running.f32(),
+                                                   n.out_c, n.out_h, n.out_w, batch, stream_));
+          break;
+        }
         if (inference)
           UNET_CALL(unet_batch_norm_inference_f32(n.z.f32(), n.bn.f32(), gb, n.running.f32(), n.out_h, n.out_w,
                                                   n.out_c, batch, stream_));
@@ -1052,9 +1059,15 @@ class Net {
         const float *w = params_.f32() + n.param_off;
         float *gw = grads_.f32() + n.param_off;
         float *g1 = scratch_g1_.f32();
-        const float *g2 = activation_backward(n, scratch_g2_.f32(), out_n);
-        UNET_CALL(unet_batch_norm_backward_f32(g2, n.z.f32(), n.batch_stats.f32(), w + n.num_wb, g1, gw + n.num_wb,
-                                               n.out_c, n.out_h, n.out_w, batch, stream_));
+        if (effective_activation(n) == ReLU) {  // ReLU backward folded into the batch-norm backward passes
+          UNET_CALL(unet_batch_norm_relu_backward_f32(n.grad_out.f32(), n.act.f32(), n.z.f32(), n.batch_stats.f32(),
+                                                      w + n.num_wb, g1, gw + n.num_wb, n.out_c, n.out_h, n.out_w, batch,
+                                                      stream_));
+        } else {
+          const float *g2 = activation_backward(n, scratch_g2_.f32(), out_n);
+          UNET_CALL(unet_batch_norm_backward_f32(g2, n.z.f32(), n.batch_stats.f32(), w + n.num_wb, g1, gw + n.num_wb,
+                                                 n.out_c, n.out_h, n.out_w, batch, stream_));
+        }
         float *dx = nullptr;
         Node *p = n.parents.empty() ? nullptr : &nodes_[n.parents[0]];
         if (p) dx = grad_target(*p);
