@@ -200,6 +200,57 @@ int main(int argc, char **argv) {
       memcpy(&u, &sn[i], 4);
       ck_stats = ck_stats * 1099511628211ull + u;
     }
+#if PIPE_LAB_STAMPS
+    {  // where a stage's time goes: clock stamps of every wave's first 32 stages (statistics variant)
+      static unsigned long long *d_st = nullptr;
+      if (!d_st) CK(hipMalloc(&d_st, (size_t)2048 * 1024 * 8));
+      CK(hipMemset(d_st, 0, (size_t)grid * 1024 * 8));
+      pipe::Args t = a;
+      t.lab_stamps = d_st;
+      if (ws)
+        hipLaunchKernelGGL((pipe::conv3x3_pipe_kernel<true, pipe::EPI_STATS>), dim3(grid), dim3(512), pipe::LDS_BYTES, 0, t);
+      else
+        hipLaunchKernelGGL((pipe::conv3x3_pipe_kernel<false, pipe::EPI_STATS>), dim3(grid), dim3(512), pipe::LDS_BYTES, 0, t);
+      CK(hipDeviceSynchronize());
+      std::vector<unsigned long long> st((size_t)grid * 1024);
+      CK(hipMemcpy(st.data(), d_st, st.size() * 8, hipMemcpyDeviceToHost));
+      // per stage s (1 .. min(stages, 32) - 2): length = t0[s+1] - t0[s]; mfma = t2 - t0; landed = t3 - t2; barrier = t0[s+1] - t3
+      double len = 0, mf = 0, land = 0, bar = 0, first = 0, total = 0;
+      long cnt = 0, wgs_seen = 0;
+      for (int g = 0; g < grid; ++g)
+        for (int w = 0; w < 8; ++w) {
+          const unsigned long long *q = &st[(size_t)g * 1024 + w * 128];
+          int ns = 0;
+          while (ns < 32 && q[ns * 4] != 0) ++ns;
+          if (ns < 4) continue;
+          ++wgs_seen;
+          total += (double)(q[(ns - 1) * 4 + 3] - q[0]);
+          for (int k = 1; k + 1 < ns; ++k) {
+            len += (double)(q[(k + 1) * 4] - q[k * 4]);
+            mf += (double)(q[k * 4 + 2] - q[k * 4]);
+            land += (double)(q[k * 4 + 3] - q[k * 4 + 2]);
+            bar += (double)(q[(k + 1) * 4] - q[k * 4 + 3]);
+            ++cnt;
+          }
+        }
+      if (getenv("LAB_STAMP_DETAIL") && s.H == atoi(getenv("LAB_STAMP_DETAIL")) && s.Ci >= 256) {
+        for (int g : {0, 100}) {
+          const unsigned long long base = st[(size_t)g * 1024];
+          for (int k = 8; k < 12; ++k) {
+            printf("    wg %3d stage %2d:", g, k);
+            for (int w = 0; w < 8; ++w) {
+              const unsigned long long *q = &st[(size_t)g * 1024 + w * 128 + k * 4];
+              printf(" w%d[%6lld +%5lld +%4lld]", w, (long long)(q[0] - base), (long long)(q[2] - q[0]), (long long)(q[3] - q[2]));
+            }
+            printf("\n");
+          }
+        }
+      }
+      if (cnt)
+        printf("  stamps %4dx%-4d %4d->%-4d: stage %7.0f = mfma phase %7.0f + operands landed %6.0f + barrier %6.0f ticks (%ld samples); stamped span per wave %.0f\n",
+               s.H, s.H, s.Ci, s.Co, len / cnt, mf / cnt, land / cnt, bar / cnt, cnt, total / wgs_seen);
+    }
+#endif
     printf("  [plain %6.1f us %5.0f TF | bred %6.1f us %5.0f TF] ", t_plain, flops / t_plain * 1e-6, t_bred, flops / t_bred * 1e-6);
     printf("%4dx%-4d %4d->%-4d %s grid %4d | library %6.1f us %5.0f TF | pipe %6.1f us %5.0f TF | mismatches %zu, stats rel %.2e | bred sums %016llx %016llx\n",
            s.H, s.H, s.Ci, s.Co, ws ? "WS" : "  ", grid, t_lib, flops / t_lib * 1e-6, t_new, flops / t_new * 1e-6, bad, worst,

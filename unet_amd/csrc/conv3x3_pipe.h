@@ -14,6 +14,16 @@
 //     out-of-image halo pixels address beyond the buffer descriptor and arrive as zeros;
 //   - twice the pixels per weight slab (512 instead of 256), and with C_in <= 64 the workgroup's whole
 //     weight block (72 KiB) stays in LDS for all of its tiles: per tile only the halo (38 KiB a chunk) moves;
+//   - nothing is computed between a stage's barrier and its first MFMA: behind the barrier come the twelve
+//     fragment reads of the first tap, back to back, then the MFMAs.  The per-lane source offsets of a tile's
+//     halo loads are set up once per tile (the K chunk goes into the loads' scalar offset), the waves that own
+//     one piece fewer than the others send that load out of range and into a spare KiB instead of branching
+//     round it, and the tile's last stage (the one that prefetches the next tile and, in the fused variants,
+//     requests the epilogue's operands) is a second copy of the stage body rather than a branch inside it;
+//   - inside a stage a wave never waits for LDS: the weight fragments of the next tap are requested before the
+//     16 MFMAs of the current one, the pixel fragments of the next tap column behind the last MFMAs that read the
+//     registers they replace; and the two halves of the workgroup request the next stage's operands at
+//     different times (see `late` in the kernel);
 //   - the epilogue has no barrier and no LDS round trip: every wave converts, stores and reduces its own
 //     8 x 16 pixel x 32 channel block (8-byte stores; batch-norm sums over the 16 pixel lanes by DPP row
 //     rotations), and writes its own row of partial sums.
@@ -22,6 +32,10 @@
 #ifndef PIPE_LAB_ABLATE
 #define PIPE_LAB_ABLATE 0  // laboratory builds only: 1 = no output stores, 2 = no MFMAs, 3 = no halo loads,
                             // 4 = no operand loads at all after the first stage (matrix cores + LDS reads only)
+#endif
+
+#ifndef PIPE_LAB_STAMPS
+#define PIPE_LAB_STAMPS 0  // laboratory builds only: clock stamps of the first 32 stages of every wave (Args::lab_stamps)
 #endif
 
 namespace pipe {
@@ -37,13 +51,14 @@ struct Geo {
   static constexpr int KH = (HALO_INSTR + 7) / 8;         // halo instructions per wave, at most
   static constexpr int STAGE_BYTES = HALO_BYTES + 9 * 64 * 64;
   static constexpr int STAGES_BYTES = 2 * STAGE_BYTES;    // (resident weights: 2 * HALO_BYTES + 2 * W_BYTES)
-  static constexpr int LDS_BYTES = STAGES_BYTES + 64 * 16;  // + the batch-norm records of the 64 channels (EPI_BRED)
+  static constexpr int DUMP_OFF = STAGES_BYTES + 64 * 16;  // behind the batch-norm records of the 64 channels (EPI_BRED)
+  static constexpr int LDS_BYTES = DUMP_OFF + 1024 + (PIPE_LAB_STAMPS ? 8192 : 0);  // + 1 KiB nobody reads (see the stage's loads)
 };
 constexpr int TH = 32;                             // the tile height of the main variant
 constexpr int W_INSTR = 9 * 64 * 4 / 64;           // 36
 constexpr int W_BYTES = W_INSTR * 1024;            // 36864: 9 taps x 64 channels x 64 B
 constexpr int MAX_WS_CHUNKS = 2;                   // weights resident in LDS up to C_in = 64
-constexpr int LDS_BYTES = Geo<32>::LDS_BYTES;      // 154624
+constexpr int LDS_BYTES = Geo<32>::LDS_BYTES;      // 155648
 
 struct Args {
   const bf16_t *in;
@@ -71,6 +86,9 @@ struct Args {
   const float4 *bcf;
   int bred_c0;
   const float4 *affine;  // AFF: per-channel {a, b, ., .}: out = relu(a * (conv + bias) + b)
+#if PIPE_LAB_STAMPS
+  unsigned long long *lab_stamps;  // [workgroup][wave][32 stages][4]: after the barrier, loads issued, MFMAs issued, operands landed
+#endif
 };
 
 __device__ __forceinline__ float row_sum16(float v) {  // sum over the 16 lanes of a DPP row, in every lane
@@ -186,34 +204,69 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pipe_kernel(const Args a) {
     y0 = ty * TH;
     x0 = (t - ty * a.tilesX) * TW;
   };
-  auto issue_weights = [&](int kc, unsigned char *dst) {
+  // A tile's halo loads: per-lane byte offsets into its image for K chunk 0 (beyond the descriptor for pixels
+  // outside the image, for pieces the layer does not have, and for a tile past the workgroup's last).
+  // (Arrays go into these lambdas as pointers: with array-reference parameters the host pass silently drops the
+  // kernel's stub.)
+  auto plan_tile = [&](int it, int &n, int &y0, int &x0, unsigned *voff) {
+    const bool live = it < my_units;
+    unit_coords(live ? it : 0, n, y0, x0);
+    const int org = ((y0 * a.W + x0) * a.in_ld) * 2;
 #pragma unroll
-    for (int k = 0; k < 5; ++k) {
-      const int j = (7 - wave) + 8 * k;
-      if (j < W_INSTR)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_ptr_t)(dst + j * 1024), 16, w_rel[k], kc * slab_bytes, 0, 0);
+    for (int k = 0; k < KH; ++k) {
+      const int py = h_pyx[k] >> 8, px = h_pyx[k] & 255;
+      const bool ok = live && h_pyx[k] >= 0 && (unsigned)(y0 + py - 1) < (unsigned)a.H && (unsigned)(x0 + px - 1) < (unsigned)a.W;
+      voff[k] = ok ? (unsigned)(org + h_rel[k]) : OOB;
     }
   };
-  auto issue_halo = [&](int it, int kc, unsigned char *dst) {
-    int n, y0, x0;
-    unit_coords(it, n, y0, x0);
+  typedef __attribute__((address_space(3))) unsigned char *lds_bytes_t;
+  const lds_bytes_t lds3 = (lds_bytes_t)lds;  // destinations as offsets from here: a select between two generic
+                                              // LDS pointers does not compile
+#if PIPE_LAB_STAMPS
+  unsigned long long *lds_stamps = reinterpret_cast<unsigned long long *>(lds + G::DUMP_OFF + 1024) + wave * 128;
+  for (int i = lane; i < 128; i += 64) lds_stamps[i] = 0;
+#define PIPE_STAMP(stage_, slot_)                                                                   \
+  do {                                                                                              \
+    if ((stage_) < 32 && lane == 0) lds_stamps[(stage_) * 4 + (slot_)] = __builtin_readcyclecounter(); \
+  } while (0)
+#else
+#define PIPE_STAMP(stage_, slot_) \
+  do {                            \
+  } while (0)
+#endif
+#if PIPE_LAB_ABLATE == 3 || PIPE_LAB_ABLATE == 4
+  int s_lab = 0;  // 0 until the first stage's operands have been requested
+#endif
+  // The loads of one stage: every wave issues KH halo pieces (and 5 weight pieces); the ones a wave does not own
+  // address beyond their descriptor and land (as zeros) in the spare KiB.  soff = the K chunk's byte offset,
+  // dst = the stage buffer's byte offset in LDS.
+  auto issue_halo = [&](int n, const unsigned *voff, int soff, int dst) {
+#if PIPE_LAB_ABLATE == 3 || PIPE_LAB_ABLATE == 4
+    if (s_lab > 0 && a.N > 0) return;
+#endif
     const auto xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(a.in) + (i64)n * a.H * a.W * a.in_ld, 0,
                                                        img_bytes, 0x00020000);
-    const int org = ((y0 * a.W + x0) * a.in_ld + kc * 32) * 2;
 #pragma unroll
     for (int k = 0; k < KH; ++k) {
       const int i = wave + 8 * k;
-      if (i < HALO_INSTR) {
-        const int py = h_pyx[k] >> 8, px = h_pyx[k] & 255;
-        const bool ok = h_pyx[k] >= 0 && (unsigned)(y0 + py - 1) < (unsigned)a.H && (unsigned)(x0 + px - 1) < (unsigned)a.W;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_ptr_t)(dst + i * 1024), 16, ok ? (unsigned)(org + h_rel[k]) : OOB,
-                                                 0, 0, 0);
-      }
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_ptr_t)(lds3 + (i < HALO_INSTR ? dst + i * 1024 : G::DUMP_OFF)), 16,
+                                               voff[k], soff, 0, 0);
     }
   };
-  auto halo_buf = [&](int s) { return lds + (WS ? (s & 1) * HALO_BYTES : (s & 1) * STAGE_BYTES); };
-  auto weight_buf = [&](int s, int kc) {
-    return WS ? lds + 2 * HALO_BYTES + kc * W_BYTES : lds + (s & 1) * STAGE_BYTES + HALO_BYTES;
+  auto issue_weights = [&](const unsigned *voff, int soff, int dst) {
+#if PIPE_LAB_ABLATE == 4
+    if (s_lab > 0 && a.N > 0) return;
+#endif
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      const int j = (7 - wave) + 8 * k;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_ptr_t)(lds3 + (j < W_INSTR ? dst + j * 1024 : G::DUMP_OFF)), 16,
+                                               voff[k], soff, 0, 0);
+    }
+  };
+  auto halo_off = [&](int s) { return WS ? (s & 1) * HALO_BYTES : (s & 1) * STAGE_BYTES; };  // byte offsets in LDS
+  auto weight_off = [&](int s, int kc) {
+    return WS ? 2 * HALO_BYTES + kc * W_BYTES : (s & 1) * STAGE_BYTES + HALO_BYTES;
   };
 
   // ---- fragment addresses (the LDS image and the loop of conv_mfma_kernel's 16x16x32 path) ----
@@ -254,12 +307,18 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pipe_kernel(const Args a) {
   const unsigned out_img_bytes = (unsigned)a.H * a.W * a.out_ld * 2u, z_img_bytes = (unsigned)a.H * a.W * a.bz_ld * 2u;
   const int stat_width = BRED ? a.CoP - a.bred_c0 : a.CoP;  // channels per row of partial sums
 
-  const int nk = a.nk, S = my_units * nk;
+  const int nk = a.nk;
+  int n, y0, x0, n_nxt, y0_nxt, x0_nxt;  // this tile and the next
+  unsigned hoff[KH], hoff_nxt[KH];
+  plan_tile(0, n, y0, x0, hoff);
   if (WS)
-    for (int kc = 0; kc < nk; ++kc) issue_weights(kc, weight_buf(0, kc));
+    for (int kc = 0; kc < nk; ++kc) issue_weights(w_rel, kc * slab_bytes, weight_off(0, kc));
   else
-    issue_weights(0, weight_buf(0, 0));
-  issue_halo(0, 0, halo_buf(0));
+    issue_weights(w_rel, 0, weight_off(0, 0));
+  issue_halo(n, hoff, 0, halo_off(0));
+#if PIPE_LAB_ABLATE == 3 || PIPE_LAB_ABLATE == 4
+  s_lab = 1;
+#endif
 
   float ssum[2][4], ssq[2][4];  // batch-norm sums of this wave's channels over all tiles of the workgroup
 #pragma unroll
@@ -268,12 +327,26 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pipe_kernel(const Args a) {
     for (int j = 0; j < 4; ++j) ssum[m][j] = ssq[m][j] = 0.f;
 
   const int ch16 = cw * 32 + (kp & 1) * 16 + (kp >> 1) * 8;  // first of the lane's 8 channels after the swap
+  // Who requests the next stage's operands when.  The two waves of a SIMD (w and w + 4) share its matrix pipe, and
+  // the arbitration goes to the older one (w < 4) whenever it has an MFMA ready: it runs through its stage first
+  // and then waits at the barrier, while the younger one does most of its MFMAs afterwards.  So the younger half
+  // issues its loads at the head of the stage, under the older half's MFMAs, and the older half -- which would
+  // otherwise spend the head of every stage issuing loads with both waves of the SIMD off the matrix pipe --
+  // issues its own after LATE_G of the nine MFMA groups, when its partner has MFMAs to fill the gap with.
+#ifndef PIPE_LATE_G
+#define PIPE_LATE_G 4  // laboratory builds: 0 = every wave at the head of the stage
+#endif
+  constexpr int LATE_G = PIPE_LATE_G;
+  const bool late = wave < 4 && LATE_G > 0;
   int s = 0;
   for (int it = 0; it < my_units; ++it) {
-    // this tile's output coordinates, and (BRED / ACC) the values its epilogue reads: requested before the
-    // last stage's MFMAs so that they have arrived when the epilogue starts
-    int n, y0, x0;
-    unit_coords(it, n, y0, x0);
+    // the next tile's halo plan (every offset out of range behind the workgroup's last tile), and the weight
+    // offsets of its first chunk
+    plan_tile(it + 1, n_nxt, y0_nxt, x0_nxt, hoff_nxt);
+    unsigned woff_nxt[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) woff_nxt[k] = it + 1 < my_units ? w_rel[k] : OOB;
+    // this tile's output coordinates
     const int x = x0 + l15;
     const i64 img = (i64)n * a.H * a.W;
     const auto ors = __builtin_amdgcn_make_buffer_rsrc(a.out + img * a.out_ld, 0, out_img_bytes, 0x00020000);
@@ -291,64 +364,117 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pipe_kernel(const Args a) {
     for (int m = 0; m < 2; ++m)
 #pragma unroll
       for (int q = 0; q < QW; ++q) acc[m][q] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int kc = 0; kc < nk; ++kc, ++s) {
-      // This wave's pieces of stage s have landed; after the barrier everybody's have, and everybody has
-      // finished reading the other buffer (stage s-1), which the next loads overwrite.  The first stage of
-      // a tile follows the previous tile's epilogue, whose stores were issued after these loads and need not
-      // be waited for.
+
+    // One stage = stage_begin, the loads of the next stage, stage_mfma.  The tile's last stage prefetches the
+    // next tile's first chunk and requests what the epilogue reads.
+    // stage_begin: this wave's pieces of stage s have landed; after the barrier everybody's have, and everybody
+    // has finished reading the other buffer (stage s-1), which the next loads overwrite.  The first stage of a
+    // tile follows the previous tile's epilogue, whose stores were issued after these loads and need not be
+    // waited for.  Then the first tap column's fragments are requested, before anything else.
+    auto stage_begin = [&](const int kc, const unsigned char *ldsX, const unsigned char *ldsW, bf16x8 *brow, bf16x8 *af) {
       if (kc == 0 && it > 0)
         wait_vmem_then_barrier<epi_vmem_ops(EPI, QW)>();
       else
         wait_vmem_then_barrier<0>();
-      if (s + 1 < S) {
-        const int it2 = (kc + 1 < nk) ? it : it + 1, kc2 = (kc + 1 < nk) ? kc + 1 : 0;
-#if PIPE_LAB_ABLATE == 4
-        if (a.N < 0)
-#endif
-        if (!WS) issue_weights(kc2, weight_buf(s + 1, kc2));
-#if PIPE_LAB_ABLATE == 3 || PIPE_LAB_ABLATE == 4
-        if (a.N < 0)
-#endif
-        issue_halo(it2, kc2, halo_buf(s + 1));
-      }
-      if ((BRED || EPI == EPI_ACC) && kc == nk - 1) {
-        if (BRED) {  // the parent's pre-BN values (zeros for the channel half that takes no part)
-          const auto zrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(a.bz) + img * a.bz_ld, 0,
-                                                             red_here ? z_img_bytes : 0u, 0x00020000);
+      PIPE_STAMP(s, 0);
 #pragma unroll
-          for (int q = 0; q < QW; ++q) {
-            const int y = y0 + ph * QW + q;
-            const unsigned zo = okq[q] ? (unsigned)(((y * a.W + x) * a.bz_ld + rc0 + ch16) * 2) : OOB;
-            zq[BRED ? q : 0] = __builtin_amdgcn_raw_buffer_load_b128(zrs, zo, 0, 0);
-          }
-        } else {
+      for (int r = 0; r < QW + 2; ++r)
+        brow[r] = *reinterpret_cast<const bf16x8 *>(ldsX + r * HC * 64 + b4_off[0][r & 3]);
 #pragma unroll
-          for (int q = 0; q < QW; ++q) oq[EPI == EPI_ACC ? q : 0] = __builtin_amdgcn_raw_buffer_load_b128(ors, ooff[q], 0, 0);
+      for (int m = 0; m < 2; ++m)
+        af[m] = *reinterpret_cast<const bf16x8 *>(ldsW + ((cw * 2 + m) * 16) * 64 + a4_lane);
+      // all twelve requests go out back to back: left to itself the scheduler pairs each read with the MFMA that
+      // needs it and the head of the stage waits for one LDS round trip per MFMA
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    // stage_mfma: nine groups of 16 MFMAs, one per tap (tap column kw outermost: the order every variant of
+    // this convolution adds in).  A wave's own stream must not wait for LDS: the older wave of a SIMD wins the
+    // arbitration for the matrix pipe and finishes its stage early, after which its partner runs alone with
+    // nobody to cover its waits.  So the weight fragments of group g+1 are requested before the MFMAs of group g,
+    // and the pixel fragments of the next tap column move in behind the last MFMAs that read the registers
+    // they replace.
+    auto stage_mfma = [&](const int g0, const int g1, const unsigned char *ldsX, const unsigned char *ldsW, bf16x8 *brow,
+                          bf16x8 *af, bf16x8 *af2) {
+#pragma unroll
+      for (int g = g0; g < g1; ++g) {
+        const int kw = g / 3, kh = g % 3;
+        bf16x8 *cur = (g & 1) ? af2 : af, *nxt = (g & 1) ? af : af2;
+        if (g < 8) {
+          const int kw2 = (g + 1) / 3, kh2 = (g + 1) % 3;
+#pragma unroll
+          for (int m = 0; m < 2; ++m)
+            nxt[m] = *reinterpret_cast<const bf16x8 *>(ldsW + ((kh2 * 3 + kw2) * 64 + (cw * 2 + m) * 16) * 64 + a4_lane);
         }
-      }
-      const unsigned char *ldsX = halo_buf(s), *ldsW = weight_buf(s, kc);
 #pragma unroll
-      for (int kw = 0; kw < 3; ++kw) {
-        bf16x8 brow[QW + 2];
-#pragma unroll
-        for (int r = 0; r < QW + 2; ++r)
-          brow[r] = *reinterpret_cast<const bf16x8 *>(ldsX + r * HC * 64 + b4_off[kw][r & 3]);
-#pragma unroll
-        for (int kh = 0; kh < 3; ++kh) {
-          bf16x8 af[2];
+        for (int q = 0; q < QW; ++q) {
 #pragma unroll
           for (int m = 0; m < 2; ++m)
-            af[m] = *reinterpret_cast<const bf16x8 *>(ldsW + ((kh * 3 + kw) * 64 + (cw * 2 + m) * 16) * 64 + a4_lane);
-#pragma unroll
-          for (int m = 0; m < 2; ++m)
-#pragma unroll
-            for (int q = 0; q < QW; ++q)
 #if PIPE_LAB_ABLATE == 2
-              if (a.N < 0)
+            if (a.N < 0)
 #endif
-              acc[m][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[m], brow[q + kh], acc[m][q], 0, 0, 0);
+            acc[m][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[m], brow[q + kh], acc[m][q], 0, 0, 0);
+          if (kh == 2 && kw < 2)
+            brow[q + 2] = *reinterpret_cast<const bf16x8 *>(ldsX + (q + 2) * HC * 64 + b4_off[kw + 1][(q + 2) & 3]);
+        }
+        if (kh < 2 && kw < 2)
+          brow[kh] = *reinterpret_cast<const bf16x8 *>(ldsX + kh * HC * 64 + b4_off[kw + 1][kh & 3]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    for (int kc = 0; kc + 1 < nk; ++kc, ++s) {
+      const unsigned char *ldsX = lds + halo_off(s), *ldsW = lds + weight_off(s, kc);
+      bf16x8 brow[QW + 2], af[2], af2[2];
+      stage_begin(kc, ldsX, ldsW, brow, af);
+      if (!late) {
+        issue_halo(n, hoff, (kc + 1) * 64, halo_off(s + 1));
+        if (!WS) issue_weights(w_rel, (kc + 1) * slab_bytes, weight_off(s + 1, kc + 1));
+      }
+      stage_mfma(0, LATE_G, ldsX, ldsW, brow, af, af2);
+      if (late) {
+        issue_halo(n, hoff, (kc + 1) * 64, halo_off(s + 1));
+        if (!WS) issue_weights(w_rel, (kc + 1) * slab_bytes, weight_off(s + 1, kc + 1));
+      }
+      stage_mfma(LATE_G, 9, ldsX, ldsW, brow, af, af2);
+#if PIPE_LAB_STAMPS
+      PIPE_STAMP(s, 2);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      PIPE_STAMP(s, 3);
+#endif
+    }
+    {
+      const unsigned char *ldsX = lds + halo_off(s), *ldsW = lds + weight_off(s, nk - 1);
+      bf16x8 brow[QW + 2], af[2], af2[2];
+      stage_begin(nk - 1, ldsX, ldsW, brow, af);
+      if (!late) {
+        issue_halo(n_nxt, hoff_nxt, 0, halo_off(s + 1));
+        if (!WS) issue_weights(woff_nxt, 0, weight_off(s + 1, 0));
+      }
+      if (BRED) {  // the parent's pre-BN values (zeros for the channel half that takes no part)
+        const auto zrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(a.bz) + img * a.bz_ld, 0,
+                                                           red_here ? z_img_bytes : 0u, 0x00020000);
+#pragma unroll
+        for (int q = 0; q < QW; ++q) {
+          const int y = y0 + ph * QW + q;
+          const unsigned zo = okq[q] ? (unsigned)(((y * a.W + x) * a.bz_ld + rc0 + ch16) * 2) : OOB;
+          zq[BRED ? q : 0] = __builtin_amdgcn_raw_buffer_load_b128(zrs, zo, 0, 0);
         }
       }
+      if (EPI == EPI_ACC) {
+#pragma unroll
+        for (int q = 0; q < QW; ++q) oq[EPI == EPI_ACC ? q : 0] = __builtin_amdgcn_raw_buffer_load_b128(ors, ooff[q], 0, 0);
+      }
+      stage_mfma(0, LATE_G, ldsX, ldsW, brow, af, af2);
+      if (late) {
+        issue_halo(n_nxt, hoff_nxt, 0, halo_off(s + 1));
+        if (!WS) issue_weights(woff_nxt, 0, weight_off(s + 1, 0));
+      }
+      stage_mfma(LATE_G, 9, ldsX, ldsW, brow, af, af2);
+#if PIPE_LAB_STAMPS
+      PIPE_STAMP(s, 2);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      PIPE_STAMP(s, 3);
+#endif
+      ++s;
     }
 
     // ---- epilogue of tile `it`: every wave on its own 8 rows x 16 pixels x 32 channels.  Buffer loads and
@@ -419,7 +545,19 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pipe_kernel(const Args a) {
         }
       }
     }
+    n = n_nxt;
+    y0 = y0_nxt;
+    x0 = x0_nxt;
+#pragma unroll
+    for (int k = 0; k < KH; ++k) hoff[k] = hoff_nxt[k];
   }
+#if PIPE_LAB_STAMPS
+  if (a.lab_stamps) {
+    __syncthreads();
+    for (int i = tid; i < 8 * 128; i += 512)
+      a.lab_stamps[(size_t)blockIdx.x * 1024 + i] = reinterpret_cast<unsigned long long *>(lds + G::DUMP_OFF + 1024)[i];
+  }
+#endif
   if (STATS && (!BRED || red_here)) {
     // One row of partial sums per (workgroup, 8-row strip position): the sums ran over all tiles of the
     // workgroup.  rows = 4 * (workgroups per channel block); lane 0 of each 16-lane row stores.
