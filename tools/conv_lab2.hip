@@ -58,7 +58,7 @@ int main(int argc, char **argv) {
   const int wgs = argc > 1 ? atoi(argv[1]) : 256;
   std::vector<Shape> shapes = {{256, 64, 64}, {256, 128, 64}, {256, 64, 128}, {128, 128, 128}, {128, 64, 128},
                                {64, 256, 256}, {32, 512, 512}, {32, 1024, 512}, {128, 256, 128}, {72, 64, 64},
-                               {16, 512, 1024}, {16, 1024, 1024}, {16, 1024, 512}};
+                               {16, 512, 1024}, {16, 1024, 1024}, {16, 1024, 512}, {256, 32, 64}};
   size_t max_in = 0, max_out = 0, max_w = 0;
   for (auto &s : shapes) {
     max_in = std::max(max_in, (size_t)N * s.H * s.H * s.Ci);
@@ -221,26 +221,31 @@ int main(int argc, char **argv) {
         for (int w = 0; w < 8; ++w) {
           const unsigned long long *q = &st[(size_t)g * 1024 + w * 128];
           int ns = 0;
-          while (ns < 32 && q[ns * 4] != 0) ++ns;
+          while (ns < 16 && q[ns * 8] != 0) ++ns;
           if (ns < 4) continue;
           ++wgs_seen;
-          total += (double)(q[(ns - 1) * 4 + 3] - q[0]);
+          total += (double)(q[(ns - 1) * 8 + 3] - q[0]);
           for (int k = 1; k + 1 < ns; ++k) {
-            len += (double)(q[(k + 1) * 4] - q[k * 4]);
-            mf += (double)(q[k * 4 + 2] - q[k * 4]);
-            land += (double)(q[k * 4 + 3] - q[k * 4 + 2]);
-            bar += (double)(q[(k + 1) * 4] - q[k * 4 + 3]);
+            len += (double)(q[(k + 1) * 8] - q[k * 8]);
+            mf += (double)(q[k * 8 + 2] - q[k * 8]);
+            land += (double)(q[k * 8 + 3] - q[k * 8 + 2]);
+            bar += (double)(q[(k + 1) * 8] - q[k * 8 + 3]);
             ++cnt;
           }
         }
-      if (getenv("LAB_STAMP_DETAIL") && s.H == atoi(getenv("LAB_STAMP_DETAIL")) && s.Ci >= 256) {
+      // LAB_STAMP_DETAIL=H,Ci: per wave [stage start relative to the workgroup's first stamp (time spent at the barrier
+      // before it), + MFMA phase, + wait for the operands, (+ epilogue, on a tile's last stage)]
+      int dh = 0, dci = 0;
+      if (getenv("LAB_STAMP_DETAIL") && sscanf(getenv("LAB_STAMP_DETAIL"), "%d,%d", &dh, &dci) == 2 && s.H == dh && s.Ci == dci) {
         for (int g : {0, 100}) {
           const unsigned long long base = st[(size_t)g * 1024];
-          for (int k = 8; k < 12; ++k) {
+          for (int k = 8; k < 14; ++k) {
             printf("    wg %3d stage %2d:", g, k);
             for (int w = 0; w < 8; ++w) {
-              const unsigned long long *q = &st[(size_t)g * 1024 + w * 128 + k * 4];
-              printf(" w%d[%6lld +%5lld +%4lld]", w, (long long)(q[0] - base), (long long)(q[2] - q[0]), (long long)(q[3] - q[2]));
+              const unsigned long long *q = &st[(size_t)g * 1024 + w * 128 + k * 8];
+              printf(" w%d[%6lld(bar %4lld) +%5lld +%4lld", w, (long long)(q[0] - base), (long long)(q[0] - q[4]), (long long)(q[2] - q[0]), (long long)(q[3] - q[2]));
+              if (q[1]) printf(" +%5lld", (long long)(q[1] - q[3]));
+              printf("]");
             }
             printf("\n");
           }

@@ -35,7 +35,7 @@
 #endif
 
 #ifndef PIPE_LAB_STAMPS
-#define PIPE_LAB_STAMPS 0  // laboratory builds only: clock stamps of the first 32 stages of every wave (Args::lab_stamps)
+#define PIPE_LAB_STAMPS 0  // laboratory builds only: clock stamps of the first 16 stages of every wave (Args::lab_stamps)
 #endif
 
 namespace pipe {
@@ -87,7 +87,7 @@ struct Args {
   int bred_c0;
   const float4 *affine;  // AFF: per-channel {a, b, ., .}: out = relu(a * (conv + bias) + b)
 #if PIPE_LAB_STAMPS
-  unsigned long long *lab_stamps;  // [workgroup][wave][32 stages][4]: after the barrier, loads issued, MFMAs issued, operands landed
+  unsigned long long *lab_stamps;  // [workgroup][wave][16 stages][8]: 0 behind the barrier, 1 epilogue done, 2 MFMAs issued, 3 operands landed, 4 before the barrier
 #endif
 };
 
@@ -174,17 +174,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pipe_kernel(const Args a) {
   // wave instruction i fills LDS bytes [1024 i, 1024 i + 1024) of its region; lane l's 16 bytes are LDS row
   // r = 16 i + l / 4, slot l % 4, which the swizzled image assigns to piece slot ^ ((r >> 1) & 3) of row r
   constexpr unsigned OOB = 0x80000000u;
-  int h_rel[KH], h_pyx[KH];  // halo: byte offset relative to the tile origin pixel; (py << 8) | px, or -1
   unsigned w_rel[5];         // weights: byte offset within one chunk's slab
-#pragma unroll
-  for (int k = 0; k < KH; ++k) {
-    const int i = wave + 8 * k;
-    const int r = 16 * i + (lane >> 2), piece = (lane & 3) ^ ((r >> 1) & 3);
-    const int py = r / HC, px = r - py * HC;
-    const bool ok = i < HALO_INSTR && r < HR * HC && (a.in_c == 0 || piece * 8 < a.in_c);
-    h_rel[k] = (((py - 1) * a.W + (px - 1)) * a.in_ld + piece * 8) * 2;
-    h_pyx[k] = ok ? ((py << 8) | px) : -1;
-  }
 #pragma unroll
   for (int k = 0; k < 5; ++k) {
     const int j = (7 - wave) + 8 * k;  // the waves with one halo instruction fewer take one weight instruction more
@@ -196,28 +186,61 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pipe_kernel(const Args a) {
   const unsigned slab_bytes = 9u * a.CoP * 64u;  // one K chunk of the packed weights
   const auto wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(a.wt), 0, slab_bytes * a.nk, 0x00020000);
 
-  auto unit_coords = [&](int it, int &n, int &y0, int &x0) {
-    int u = wgi + it * nwg;
-    if (a.reverse) u = a.units - 1 - u;
+  // The workgroup's tiles: unit u = wgi + it * nwg (counted from the last unit if a.reverse) = (image n, tile row
+  // ty, tile column tx), tx fastest.  One pair of divisions here; the walk then steps by nwg units with carries.
+  const int step_n = nwg / tpi, step_r = nwg - step_n * tpi, step_ty = step_r / a.tilesX, step_tx = step_r - step_ty * a.tilesX;
+  auto first_unit = [&](int &n, int &ty, int &tx) __attribute__((always_inline)) {
+    const int u = a.reverse ? a.units - 1 - wgi : wgi;
     n = u / tpi;
-    const int t = u - n * tpi, ty = t / a.tilesX;
-    y0 = ty * TH;
-    x0 = (t - ty * a.tilesX) * TW;
+    const int t = u - n * tpi;
+    ty = t / a.tilesX;
+    tx = t - ty * a.tilesX;
+  };
+  auto next_unit = [&](int &n, int &ty, int &tx) __attribute__((always_inline)) {
+    if (a.reverse) {
+      tx -= step_tx;
+      if (tx < 0) tx += a.tilesX, --ty;
+      ty -= step_ty;
+      if (ty < 0) ty += a.tilesY, --n;
+      n -= step_n;
+    } else {
+      tx += step_tx;
+      if (tx >= a.tilesX) tx -= a.tilesX, ++ty;
+      ty += step_ty;
+      if (ty >= a.tilesY) ty -= a.tilesY, ++n;
+      n += step_n;
+    }
   };
   // A tile's halo loads: per-lane byte offsets into its image for K chunk 0 (beyond the descriptor for pixels
-  // outside the image, for pieces the layer does not have, and for a tile past the workgroup's last).
-  // (Arrays go into these lambdas as pointers: with array-reference parameters the host pass silently drops the
-  // kernel's stub.)
-  auto plan_tile = [&](int it, int &n, int &y0, int &x0, unsigned *voff) {
-    const bool live = it < my_units;
-    unit_coords(live ? it : 0, n, y0, x0);
-    const int org = ((y0 * a.W + x0) * a.in_ld) * 2;
+  // outside the image, for pieces the layer does not have, and -- live = false -- for a tile past the
+  // workgroup's last).  (Arrays go into these lambdas as pointers: with array-reference parameters the host pass
+  // silently drops the kernel's stub.)
+  // plan_piece: halo load k of this wave (KH per tile); plan_tile: all of them.  hk[k] = the piece's halo row, halo
+  // column and 16-byte slot, packed (or -1 for a piece this wave does not own or the layer does not have): one
+  // register per piece instead of the offsets they expand to.  No short-circuit evaluation: a handful of vector
+  // instructions without branches.
+  int hk[KH];
 #pragma unroll
-    for (int k = 0; k < KH; ++k) {
-      const int py = h_pyx[k] >> 8, px = h_pyx[k] & 255;
-      const bool ok = live && h_pyx[k] >= 0 && (unsigned)(y0 + py - 1) < (unsigned)a.H && (unsigned)(x0 + px - 1) < (unsigned)a.W;
-      voff[k] = ok ? (unsigned)(org + h_rel[k]) : OOB;
-    }
+  for (int k = 0; k < KH; ++k) {
+    const int i = wave + 8 * k;
+    const int r = 16 * i + (lane >> 2), piece = (lane & 3) ^ ((r >> 1) & 3);
+    const int py = r / HC, px = r - py * HC;
+    const bool ok = i < HALO_INSTR && r < HR * HC && (a.in_c == 0 || piece * 8 < a.in_c);
+    hk[k] = ok ? ((py << 16) | (px << 8) | piece) : -1;
+  }
+  auto plan_piece = [&](const int k, bool live, int y0, int x0, unsigned *voff) __attribute__((always_inline)) {
+    const int org = (((y0 - 1) * a.W + (x0 - 1)) * a.in_ld) * 2;
+    int h = hk[k];
+    asm volatile("" : "+v"(h));  // expanded per tile: hoisted out of the tile loop, the terms below would sit in
+                                 // registers of their own through every stage
+    const int py = h >> 16, px = (h >> 8) & 255, piece = h & 255;
+    const int ok = (int)live & (int)(h >= 0) & (int)((unsigned)(y0 + py - 1) < (unsigned)a.H) &
+                   (int)((unsigned)(x0 + px - 1) < (unsigned)a.W);
+    voff[k] = ok ? (unsigned)(org + ((py * a.W + px) * a.in_ld + piece * 8) * 2) : OOB;
+  };
+  auto plan_tile = [&](bool live, int y0, int x0, unsigned *voff) __attribute__((always_inline)) {
+#pragma unroll
+    for (int k = 0; k < KH; ++k) plan_piece(k, live, y0, x0, voff);
   };
   typedef __attribute__((address_space(3))) unsigned char *lds_bytes_t;
   const lds_bytes_t lds3 = (lds_bytes_t)lds;  // destinations as offsets from here: a select between two generic
@@ -227,7 +250,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pipe_kernel(const Args a) {
   for (int i = lane; i < 128; i += 64) lds_stamps[i] = 0;
 #define PIPE_STAMP(stage_, slot_)                                                                   \
   do {                                                                                              \
-    if ((stage_) < 32 && lane == 0) lds_stamps[(stage_) * 4 + (slot_)] = __builtin_readcyclecounter(); \
+    if ((stage_) < 16 && lane == 0) lds_stamps[(stage_) * 8 + (slot_)] = __builtin_readcyclecounter(); \
   } while (0)
 #else
 #define PIPE_STAMP(stage_, slot_) \
@@ -240,7 +263,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pipe_kernel(const Args a) {
   // The loads of one stage: every wave issues KH halo pieces (and 5 weight pieces); the ones a wave does not own
   // address beyond their descriptor and land (as zeros) in the spare KiB.  soff = the K chunk's byte offset,
   // dst = the stage buffer's byte offset in LDS.
-  auto issue_halo = [&](int n, const unsigned *voff, int soff, int dst) {
+  auto issue_halo = [&](int n, const unsigned *voff, int soff, int dst) __attribute__((always_inline)) {
 #if PIPE_LAB_ABLATE == 3 || PIPE_LAB_ABLATE == 4
     if (s_lab > 0 && a.N > 0) return;
 #endif
@@ -253,7 +276,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pipe_kernel(const Args a) {
                                                voff[k], soff, 0, 0);
     }
   };
-  auto issue_weights = [&](const unsigned *voff, int soff, int dst) {
+  auto issue_weights = [&](const unsigned *voff, int soff, int dst) __attribute__((always_inline)) {
 #if PIPE_LAB_ABLATE == 4
     if (s_lab > 0 && a.N > 0) return;
 #endif
@@ -264,8 +287,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pipe_kernel(const Args a) {
                                                voff[k], soff, 0, 0);
     }
   };
-  auto halo_off = [&](int s) { return WS ? (s & 1) * HALO_BYTES : (s & 1) * STAGE_BYTES; };  // byte offsets in LDS
-  auto weight_off = [&](int s, int kc) {
+  auto halo_off = [&](int s) __attribute__((always_inline)) { return WS ? (s & 1) * HALO_BYTES : (s & 1) * STAGE_BYTES; };  // byte offsets in LDS
+  auto weight_off = [&](int s, int kc) __attribute__((always_inline)) {
     return WS ? 2 * HALO_BYTES + kc * W_BYTES : (s & 1) * STAGE_BYTES + HALO_BYTES;
   };
 
@@ -308,9 +331,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pipe_kernel(const Args a) {
   const int stat_width = BRED ? a.CoP - a.bred_c0 : a.CoP;  // channels per row of partial sums
 
   const int nk = a.nk;
-  int n, y0, x0, n_nxt, y0_nxt, x0_nxt;  // this tile and the next
+  int n, ty, tx;  // the current tile
   unsigned hoff[KH], hoff_nxt[KH];
-  plan_tile(0, n, y0, x0, hoff);
+  first_unit(n, ty, tx);
+  plan_tile(true, ty * TH, tx * TW, hoff);
   if (WS)
     for (int kc = 0; kc < nk; ++kc) issue_weights(w_rel, kc * slab_bytes, weight_off(0, kc));
   else
@@ -332,156 +356,43 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pipe_kernel(const Args a) {
   // and then waits at the barrier, while the younger one does most of its MFMAs afterwards.  So the younger half
   // issues its loads at the head of the stage, under the older half's MFMAs, and the older half -- which would
   // otherwise spend the head of every stage issuing loads with both waves of the SIMD off the matrix pipe --
-  // issues its own after LATE_G of the nine MFMA groups, when its partner has MFMAs to fill the gap with.
+  // issues its own after LATE_G of the nine MFMA groups, when its partner has MFMAs to fill the gap with.  Not so
+  // in the fused-reduction variant of the layers with resident weights (few channels, full-resolution images: the
+  // memory-bound ones, whose last stage also requests the epilogue's operands): measured 2 - 6 % faster with every
+  // load out at the head of the stage.
+  // (Not done, because measured slower: the younger half writing a finished tile behind the next tile's first
+  // barrier instead of with the SIMD waiting for it -- under its partner's MFMAs that epilogue takes twice as
+  // long, and the stage it sits in grows by more than the tile's end saves.)
 #ifndef PIPE_LATE_G
 #define PIPE_LATE_G 4  // laboratory builds: 0 = every wave at the head of the stage
 #endif
-  constexpr int LATE_G = PIPE_LATE_G;
+  constexpr int LATE_G = (WS && BRED) ? 0 : PIPE_LATE_G;
   const bool late = wave < 4 && LATE_G > 0;
-  int s = 0;
-  for (int it = 0; it < my_units; ++it) {
-    // the next tile's halo plan (every offset out of range behind the workgroup's last tile), and the weight
-    // offsets of its first chunk
-    plan_tile(it + 1, n_nxt, y0_nxt, x0_nxt, hoff_nxt);
-    unsigned woff_nxt[5];
-#pragma unroll
-    for (int k = 0; k < 5; ++k) woff_nxt[k] = it + 1 < my_units ? w_rel[k] : OOB;
-    // this tile's output coordinates
-    const int x = x0 + l15;
-    const i64 img = (i64)n * a.H * a.W;
-    const auto ors = __builtin_amdgcn_make_buffer_rsrc(a.out + img * a.out_ld, 0, out_img_bytes, 0x00020000);
-    unsigned ooff[QW];  // byte offset of the lane's 16 bytes in the output image, or OOB
-    bool okq[QW];
+
+  i32x4 zq[BRED ? QW : 1], oq[EPI == EPI_ACC ? QW : 1];  // what the epilogue reads, requested in a tile's last stage
+  f32x4 acc[2][QW];
+  // Output addressing of tile (en, ety, etx): the lane's 16 bytes of row q, or out of range
+  auto out_offsets = [&](int ety, int etx, unsigned *ooff, bool *okq, int ld, int c0) __attribute__((always_inline)) {
+    int lx = l15;
+    asm volatile("" : "+v"(lx));  // keeps the eight per-row offsets from being hoisted out of the tile loop
+    const int x = etx * TW + lx;
 #pragma unroll
     for (int q = 0; q < QW; ++q) {
-      const int y = y0 + ph * QW + q;
+      const int y = ety * TH + ph * QW + q;
       okq[q] = y < a.H && x < a.W;
-      ooff[q] = okq[q] ? (unsigned)(((y * a.W + x) * a.out_ld + co0 + ch16) * 2) : OOB;
+      ooff[q] = okq[q] ? (unsigned)(((y * a.W + x) * ld + c0 + ch16) * 2) : OOB;
     }
-    i32x4 zq[BRED ? QW : 1], oq[EPI == EPI_ACC ? QW : 1];
-    f32x4 acc[2][QW];
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-      for (int q = 0; q < QW; ++q) acc[m][q] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    // One stage = stage_begin, the loads of the next stage, stage_mfma.  The tile's last stage prefetches the
-    // next tile's first chunk and requests what the epilogue reads.
-    // stage_begin: this wave's pieces of stage s have landed; after the barrier everybody's have, and everybody
-    // has finished reading the other buffer (stage s-1), which the next loads overwrite.  The first stage of a
-    // tile follows the previous tile's epilogue, whose stores were issued after these loads and need not be
-    // waited for.  Then the first tap column's fragments are requested, before anything else.
-    auto stage_begin = [&](const int kc, const unsigned char *ldsX, const unsigned char *ldsW, bf16x8 *brow, bf16x8 *af) {
-      if (kc == 0 && it > 0)
-        wait_vmem_then_barrier<epi_vmem_ops(EPI, QW)>();
-      else
-        wait_vmem_then_barrier<0>();
-      PIPE_STAMP(s, 0);
-#pragma unroll
-      for (int r = 0; r < QW + 2; ++r)
-        brow[r] = *reinterpret_cast<const bf16x8 *>(ldsX + r * HC * 64 + b4_off[0][r & 3]);
-#pragma unroll
-      for (int m = 0; m < 2; ++m)
-        af[m] = *reinterpret_cast<const bf16x8 *>(ldsW + ((cw * 2 + m) * 16) * 64 + a4_lane);
-      // all twelve requests go out back to back: left to itself the scheduler pairs each read with the MFMA that
-      // needs it and the head of the stage waits for one LDS round trip per MFMA
-      __builtin_amdgcn_sched_barrier(0);
-    };
-    // stage_mfma: nine groups of 16 MFMAs, one per tap (tap column kw outermost: the order every variant of
-    // this convolution adds in).  A wave's own stream must not wait for LDS: the older wave of a SIMD wins the
-    // arbitration for the matrix pipe and finishes its stage early, after which its partner runs alone with
-    // nobody to cover its waits.  So the weight fragments of group g+1 are requested before the MFMAs of group g,
-    // and the pixel fragments of the next tap column move in behind the last MFMAs that read the registers
-    // they replace.
-    auto stage_mfma = [&](const int g0, const int g1, const unsigned char *ldsX, const unsigned char *ldsW, bf16x8 *brow,
-                          bf16x8 *af, bf16x8 *af2) {
-#pragma unroll
-      for (int g = g0; g < g1; ++g) {
-        const int kw = g / 3, kh = g % 3;
-        bf16x8 *cur = (g & 1) ? af2 : af, *nxt = (g & 1) ? af : af2;
-        if (g < 8) {
-          const int kw2 = (g + 1) / 3, kh2 = (g + 1) % 3;
-#pragma unroll
-          for (int m = 0; m < 2; ++m)
-            nxt[m] = *reinterpret_cast<const bf16x8 *>(ldsW + ((kh2 * 3 + kw2) * 64 + (cw * 2 + m) * 16) * 64 + a4_lane);
-        }
-#pragma unroll
-        for (int q = 0; q < QW; ++q) {
-#pragma unroll
-          for (int m = 0; m < 2; ++m)
-#if PIPE_LAB_ABLATE == 2
-            if (a.N < 0)
-#endif
-            acc[m][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[m], brow[q + kh], acc[m][q], 0, 0, 0);
-          if (kh == 2 && kw < 2)
-            brow[q + 2] = *reinterpret_cast<const bf16x8 *>(ldsX + (q + 2) * HC * 64 + b4_off[kw + 1][(q + 2) & 3]);
-        }
-        if (kh < 2 && kw < 2)
-          brow[kh] = *reinterpret_cast<const bf16x8 *>(ldsX + kh * HC * 64 + b4_off[kw + 1][kh & 3]);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    };
-    for (int kc = 0; kc + 1 < nk; ++kc, ++s) {
-      const unsigned char *ldsX = lds + halo_off(s), *ldsW = lds + weight_off(s, kc);
-      bf16x8 brow[QW + 2], af[2], af2[2];
-      stage_begin(kc, ldsX, ldsW, brow, af);
-      if (!late) {
-        issue_halo(n, hoff, (kc + 1) * 64, halo_off(s + 1));
-        if (!WS) issue_weights(w_rel, (kc + 1) * slab_bytes, weight_off(s + 1, kc + 1));
-      }
-      stage_mfma(0, LATE_G, ldsX, ldsW, brow, af, af2);
-      if (late) {
-        issue_halo(n, hoff, (kc + 1) * 64, halo_off(s + 1));
-        if (!WS) issue_weights(w_rel, (kc + 1) * slab_bytes, weight_off(s + 1, kc + 1));
-      }
-      stage_mfma(LATE_G, 9, ldsX, ldsW, brow, af, af2);
-#if PIPE_LAB_STAMPS
-      PIPE_STAMP(s, 2);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      PIPE_STAMP(s, 3);
-#endif
-    }
-    {
-      const unsigned char *ldsX = lds + halo_off(s), *ldsW = lds + weight_off(s, nk - 1);
-      bf16x8 brow[QW + 2], af[2], af2[2];
-      stage_begin(nk - 1, ldsX, ldsW, brow, af);
-      if (!late) {
-        issue_halo(n_nxt, hoff_nxt, 0, halo_off(s + 1));
-        if (!WS) issue_weights(woff_nxt, 0, weight_off(s + 1, 0));
-      }
-      if (BRED) {  // the parent's pre-BN values (zeros for the channel half that takes no part)
-        const auto zrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(a.bz) + img * a.bz_ld, 0,
-                                                           red_here ? z_img_bytes : 0u, 0x00020000);
-#pragma unroll
-        for (int q = 0; q < QW; ++q) {
-          const int y = y0 + ph * QW + q;
-          const unsigned zo = okq[q] ? (unsigned)(((y * a.W + x) * a.bz_ld + rc0 + ch16) * 2) : OOB;
-          zq[BRED ? q : 0] = __builtin_amdgcn_raw_buffer_load_b128(zrs, zo, 0, 0);
-        }
-      }
-      if (EPI == EPI_ACC) {
-#pragma unroll
-        for (int q = 0; q < QW; ++q) oq[EPI == EPI_ACC ? q : 0] = __builtin_amdgcn_raw_buffer_load_b128(ors, ooff[q], 0, 0);
-      }
-      stage_mfma(0, LATE_G, ldsX, ldsW, brow, af, af2);
-      if (late) {
-        issue_halo(n_nxt, hoff_nxt, 0, halo_off(s + 1));
-        if (!WS) issue_weights(woff_nxt, 0, weight_off(s + 1, 0));
-      }
-      stage_mfma(LATE_G, 9, ldsX, ldsW, brow, af, af2);
-#if PIPE_LAB_STAMPS
-      PIPE_STAMP(s, 2);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      PIPE_STAMP(s, 3);
-#endif
-      ++s;
-    }
-
-    // ---- epilogue of tile `it`: every wave on its own 8 rows x 16 pixels x 32 channels.  Buffer loads and
-    // stores whose out-of-image lanes address beyond the descriptor: no branches, and a fixed number of
-    // vector-memory instructions per tile (epi_vmem_ops).  The matrix cores leave a lane with 4 channels of
-    // each of its two 16-channel blocks; v_permlane16_swap between lanes 16 apart turns that into 8
-    // consecutive channels of one block, so a lane moves 16 bytes and a pixel's 64 bytes leave in one piece.
+  };
+  // ---- epilogue of tile (en, ety, etx): every wave on its own 8 rows x 16 pixels x 32 channels.  Buffer loads
+  // and stores whose out-of-image lanes address beyond the descriptor: no branches, and a fixed number of
+  // vector-memory instructions per tile (epi_vmem_ops).  The matrix cores leave a lane with 4 channels of
+  // each of its two 16-channel blocks; v_permlane16_swap between lanes 16 apart turns that into 8
+  // consecutive channels of one block, so a lane moves 16 bytes and a pixel's 64 bytes leave in one piece.
+  auto epilogue = [&](const int en, const int ety, const int etx, const int stamp_stage) __attribute__((always_inline)) {
+    const auto ors = __builtin_amdgcn_make_buffer_rsrc(a.out + (i64)en * a.H * a.W * a.out_ld, 0, out_img_bytes, 0x00020000);
+    unsigned ooff[QW];
+    bool okq[QW];
+    out_offsets(ety, etx, ooff, okq, a.out_ld, co0);
     float4 bcf[BRED ? 8 : 1];
     if (BRED) {
 #pragma unroll
@@ -545,9 +456,132 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pipe_kernel(const Args a) {
         }
       }
     }
-    n = n_nxt;
-    y0 = y0_nxt;
-    x0 = x0_nxt;
+    PIPE_STAMP(stamp_stage, 1);
+  };
+
+  // A stage: barrier, fragment reads, the loads of the next stage, nine groups of 16 MFMAs (one per tap; tap
+  // column kw outermost: the order every variant of this convolution adds in).
+  // head_reads: the first tap's fragments (ten pixel rows, two weight blocks), requested back to back: left to
+  // itself the scheduler pairs each read with the MFMA that needs it and the head of the stage waits for one
+  // LDS round trip per MFMA.
+  auto head_reads = [&](const unsigned char *ldsX, const unsigned char *ldsW, bf16x8 *brow, bf16x8 *af) __attribute__((always_inline)) {
+#pragma unroll
+    for (int r = 0; r < QW + 2; ++r)
+      brow[r] = *reinterpret_cast<const bf16x8 *>(ldsX + r * HC * 64 + b4_off[0][r & 3]);
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+      af[m] = *reinterpret_cast<const bf16x8 *>(ldsW + ((cw * 2 + m) * 16) * 64 + a4_lane);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  // stage_mfma: groups g0 .. g1-1.  A wave's own stream must not wait for LDS: once the older wave of the SIMD
+  // is through its stage, the younger one runs alone with nobody to cover its waits.  So the weight fragments of
+  // group g+1 are requested before the MFMAs of group g, and the pixel fragments of the next tap column move in
+  // behind the last MFMAs that read the registers they replace.
+  // zero_start: group 0 starts the tile's sums (the MFMA's addend is the constant zero instead of the accumulator:
+  // no accumulator is cleared anywhere).
+  auto stage_mfma = [&](const int g0, const int g1, const bool zero_start, const unsigned char *ldsX, const unsigned char *ldsW,
+                        bf16x8 *brow, bf16x8 *af, bf16x8 *af2) __attribute__((always_inline)) {
+#pragma unroll
+    for (int g = g0; g < g1; ++g) {
+      const int kw = g / 3, kh = g % 3;
+      bf16x8 *cur = (g & 1) ? af2 : af, *nxt = (g & 1) ? af : af2;
+      if (g < 8) {
+        const int kw2 = (g + 1) / 3, kh2 = (g + 1) % 3;
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+          nxt[m] = *reinterpret_cast<const bf16x8 *>(ldsW + ((kh2 * 3 + kw2) * 64 + (cw * 2 + m) * 16) * 64 + a4_lane);
+      }
+#pragma unroll
+      for (int q = 0; q < QW; ++q) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#if PIPE_LAB_ABLATE == 2
+          if (a.N < 0)
+#endif
+          acc[m][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[m], brow[q + kh],
+                                                              (zero_start && g == 0) ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[m][q], 0, 0, 0);
+        if (kh == 2 && kw < 2)
+          brow[q + 2] = *reinterpret_cast<const bf16x8 *>(ldsX + (q + 2) * HC * 64 + b4_off[kw + 1][(q + 2) & 3]);
+      }
+      if (kh < 2 && kw < 2)
+        brow[kh] = *reinterpret_cast<const bf16x8 *>(ldsX + kh * HC * 64 + b4_off[kw + 1][kh & 3]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+  int s = 0;
+  for (int it = 0; it < my_units; ++it) {
+    // the next tile's halo plan (every offset out of range behind the workgroup's last tile), and the weight
+    // offsets of its first chunk
+    const bool more = it + 1 < my_units;
+    int n_nxt = n, ty_nxt = ty, tx_nxt = tx;
+    if (more) next_unit(n_nxt, ty_nxt, tx_nxt);
+    plan_tile(more, ty_nxt * TH, tx_nxt * TW, hoff_nxt);
+    unsigned woff_nxt[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) woff_nxt[k] = more ? w_rel[k] : OOB;
+
+    // One stage of the tile (first / last: literal at every call, so each combination is straight-line code).
+    // Opening: this wave's pieces of stage s have landed and its LDS reads of stage s-1 are complete; after the
+    // barrier everybody's are, so stage s may be read and the other buffer overwritten.  The first stage of a
+    // tile follows the previous tile's epilogue, whose stores were issued after these loads and need not be
+    // waited for.  The tile's last stage prefetches the next tile's first chunk and requests what the epilogue
+    // reads.
+    auto stage = [&](const bool first, const bool last, const int kc) __attribute__((always_inline)) {
+      const unsigned char *ldsX = lds + halo_off(s), *ldsW = lds + weight_off(s, kc);
+      bf16x8 brow[QW + 2], af[2], af2[2];
+      const int hn = last ? n_nxt : n, hs = last ? 0 : (kc + 1) * 64, ws_ = last ? 0 : (kc + 1) * slab_bytes;
+      const unsigned *hv = last ? hoff_nxt : hoff, *wv = last ? woff_nxt : w_rel;
+      const int dst_h = halo_off(s + 1), dst_w = weight_off(s + 1, last ? 0 : kc + 1);
+      PIPE_STAMP(s, 4);
+      if (first && it > 0)
+        wait_vmem_then_barrier<epi_vmem_ops(EPI, QW)>();
+      else
+        wait_vmem_then_barrier<0>();
+      PIPE_STAMP(s, 0);
+      head_reads(ldsX, ldsW, brow, af);
+      if (!late) {
+        issue_halo(hn, hv, hs, dst_h);
+        if (!WS) issue_weights(wv, ws_, dst_w);
+      }
+      if (last && (BRED || EPI == EPI_ACC)) {
+        unsigned eoff[QW];
+        bool okq[QW];
+        if (BRED) {  // the parent's pre-BN values (zeros for the channel half that takes no part)
+          const auto zrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t *>(a.bz) + (i64)n * a.H * a.W * a.bz_ld, 0,
+                                                             red_here ? z_img_bytes : 0u, 0x00020000);
+          out_offsets(ty, tx, eoff, okq, a.bz_ld, rc0);
+#pragma unroll
+          for (int q = 0; q < QW; ++q) zq[BRED ? q : 0] = __builtin_amdgcn_raw_buffer_load_b128(zrs, eoff[q], 0, 0);
+        } else {
+          const auto ors = __builtin_amdgcn_make_buffer_rsrc(a.out + (i64)n * a.H * a.W * a.out_ld, 0, out_img_bytes, 0x00020000);
+          out_offsets(ty, tx, eoff, okq, a.out_ld, co0);
+#pragma unroll
+          for (int q = 0; q < QW; ++q) oq[EPI == EPI_ACC ? q : 0] = __builtin_amdgcn_raw_buffer_load_b128(ors, eoff[q], 0, 0);
+        }
+      }
+      stage_mfma(0, LATE_G, first, ldsX, ldsW, brow, af, af2);
+      if (late) {
+        issue_halo(hn, hv, hs, dst_h);
+        if (!WS) issue_weights(wv, ws_, dst_w);
+      }
+      stage_mfma(LATE_G, 9, first && LATE_G == 0, ldsX, ldsW, brow, af, af2);
+#if PIPE_LAB_STAMPS
+      PIPE_STAMP(s, 2);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      PIPE_STAMP(s, 3);
+#endif
+      ++s;
+    };
+    if (nk == 1) {
+      stage(true, true, 0);
+    } else {
+      stage(true, false, 0);
+      for (int kc = 1; kc + 1 < nk; ++kc) stage(false, false, kc);
+      stage(false, true, nk - 1);
+    }
+    epilogue(n, ty, tx, s - 1);
+    n = n_nxt, ty = ty_nxt, tx = tx_nxt;
 #pragma unroll
     for (int k = 0; k < KH; ++k) hoff[k] = hoff_nxt[k];
   }
