@@ -344,11 +344,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pipe_kernel(const Args a) {
   s_lab = 1;
 #endif
 
-  float ssum[2][4], ssq[2][4];  // batch-norm sums of this wave's channels over all tiles of the workgroup
+  // batch-norm sums over all tiles of the workgroup, kept in the layout the results are STORED in: the lane's 8
+  // consecutive channels (from ch16, below) of its pixel column
+  float ssum[8], ssq[8];
 #pragma unroll
-  for (int m = 0; m < 2; ++m)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) ssum[m][j] = ssq[m][j] = 0.f;
+  for (int j = 0; j < 8; ++j) ssum[j] = ssq[j] = 0.f;
 
   const int ch16 = cw * 32 + (kp & 1) * 16 + (kp >> 1) * 8;  // first of the lane's 8 channels after the swap
   // Who requests the next stage's operands when.  The two waves of a SIMD (w and w + 4) share its matrix pipe, and
@@ -396,18 +396,38 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pipe_kernel(const Args a) {
     float4 bcf[BRED ? 8 : 1];
     if (BRED) {
 #pragma unroll
-      for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) bcf[BRED ? m * 4 + j : 0] = lds_cf[(cw * 2 + m) * 16 + 4 * kp + j];
+      for (int j = 0; j < 8; ++j) bcf[BRED ? j : 0] = lds_cf[ch16 + j];
     }
+    // a tile that lies inside the image (every tile of an image whose sides are multiples of the tile's) needs no
+    // per-pixel masks in its statistics
+    const bool inside = ety * TH + TH <= a.H && etx * TW + TW <= a.W;
+    // Statistics of one stored row (sw = the lane's 8 rounded channels, z = BRED: the parent's pre-BN values of
+    // the same 8 channels).  They run on what is stored, after the exchange between lanes: no second copy of the
+    // results in the matrix cores' layout, and the fused reduction's operands need no exchange at all.
+    auto row_stats = [&](const i32x4 &sw, const i32x4 &z, const bool masked, const bool ok) __attribute__((always_inline)) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const unsigned w = (unsigned)sw[j >> 1];
+        float r = (j & 1) ? bf16_to_f32(w >> 16) : bf16_to_f32(w & 0xffffu);  // statistics of the ROUNDED values
+        if (masked && !ok) r = 0.f;
+        if (BRED) {
+          const unsigned zz = (unsigned)z[j >> 1];
+          const float zv = (j & 1) ? bf16_to_f32(zz >> 16) : bf16_to_f32(zz & 0xffffu);
+          const float4 c = bcf[BRED ? j : 0];
+          const float g = fmaf(c.x, zv, c.y) > 0.f ? r : 0.f;
+          ssum[j] = fmaf(g, zv, ssum[j]);  // sum g*z; turned into sum g*xhat at the end
+          ssq[j] += g;
+        } else {
+          ssum[j] += r;
+          ssq[j] += r * r;
+        }
+      }
+    };
+    i32x4 stored[STATS ? QW : 1];
 #pragma unroll
     for (int q = 0; q < QW; ++q) {
       typedef u32x2_t u32x2;
-      u32x2 hw[2];   // the rounded result, matrix-core layout: hw[m] = 4 channels of block m
-      f32x4 rv[2];   // the same as floats (what the statistics see)
-      u32x2 ow[2] = {u32x2{0, 0}, u32x2{0, 0}}, zw[2] = {u32x2{0, 0}, u32x2{0, 0}};
-      if (EPI == EPI_ACC) unswap16(oq[EPI == EPI_ACC ? q : 0], ow);
-      if (BRED) unswap16(zq[BRED ? q : 0], zw);
+      u32x2 hw[2];  // the rounded result, matrix-core layout: hw[m] = 4 channels of block m
 #pragma unroll
       for (int m = 0; m < 2; ++m) {
         f32x4 v = acc[m][q];
@@ -417,43 +437,35 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pipe_kernel(const Args a) {
         } else if (!BRED) {
           v += biasv[m];
         }
-        bf16x4 h = __builtin_convertvector(v, bf16x4);
-        if (EPI == EPI_ACC)
-          h = __builtin_convertvector(__builtin_convertvector(h, f32x4) +
-                                          __builtin_convertvector(__builtin_bit_cast(bf16x4, ow[m]), f32x4), bf16x4);
-        hw[m] = __builtin_bit_cast(u32x2, h);
-        rv[m] = __builtin_convertvector(h, f32x4);
+        hw[m] = __builtin_bit_cast(u32x2, __builtin_convertvector(v, bf16x4));
+      }
+      i32x4 sw = swap16(hw);
+      if (EPI == EPI_ACC) {  // + what the output holds (same layout), rounded again
+        const i32x4 o = oq[EPI == EPI_ACC ? q : 0];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+          const unsigned x0_ = (unsigned)sw[d], x1_ = (unsigned)o[d];
+          const float lo = bf16_to_f32(x0_ & 0xffffu) + bf16_to_f32(x1_ & 0xffffu);
+          const float hi = bf16_to_f32(x0_ >> 16) + bf16_to_f32(x1_ >> 16);
+          sw[d] = (int)((unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16));
+        }
       }
 #if PIPE_LAB_ABLATE == 1
       if (a.N < 0)
 #endif
       if (a.nt_store)
-        __builtin_amdgcn_raw_buffer_store_b128(swap16(hw), ors, ooff[q], 0, 2);  // cache policy bit 1: nt
+        __builtin_amdgcn_raw_buffer_store_b128(sw, ors, ooff[q], 0, 2);  // cache policy bit 1: nt
       else
-        __builtin_amdgcn_raw_buffer_store_b128(swap16(hw), ors, ooff[q], 0, 0);
-      if (STATS) {
+        __builtin_amdgcn_raw_buffer_store_b128(sw, ors, ooff[q], 0, 0);
+      if (STATS) stored[STATS ? q : 0] = sw;
+    }
+    if (STATS) {
+      if (inside) {
 #pragma unroll
-        for (int m = 0; m < 2; ++m) {
-          f32x4 r = rv[m];  // statistics of the ROUNDED values
-          if (!okq[q]) r = f32x4{0.f, 0.f, 0.f, 0.f};
-          if (BRED) {
-            const unsigned zz[2] = {zw[m].x, zw[m].y};
+        for (int q = 0; q < QW; ++q) row_stats(stored[STATS ? q : 0], zq[BRED ? q : 0], false, true);
+      } else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              const float zv = (j & 1) ? bf16_to_f32(zz[j >> 1] >> 16) : bf16_to_f32(zz[j >> 1] & 0xffffu);
-              const float4 c = bcf[BRED ? m * 4 + j : 0];
-              const float g = fmaf(c.x, zv, c.y) > 0.f ? r[j] : 0.f;
-              ssum[m][j] = fmaf(g, zv, ssum[m][j]);  // sum g*z; turned into sum g*xhat at the end
-              ssq[m][j] += g;
-            }
-          } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              ssum[m][j] += r[j];
-              ssq[m][j] += r[j] * r[j];
-            }
-          }
-        }
+        for (int q = 0; q < QW; ++q) row_stats(stored[STATS ? q : 0], zq[BRED ? q : 0], true, okq[q]);
       }
     }
     PIPE_STAMP(stamp_stage, 1);
@@ -596,24 +608,22 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pipe_kernel(const Args a) {
     // One row of partial sums per (workgroup, 8-row strip position): the sums ran over all tiles of the
     // workgroup.  rows = 4 * (workgroups per channel block); lane 0 of each 16-lane row stores.
     float *row = a.stats + ((i64)(wgi * 4 + ph) * stat_width + (BRED ? rc0 : co0)) * 2;
+    float o[16];
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {
-      float o[8];
+    for (int j = 0; j < 8; ++j) {
+      float sv = row_sum16(ssum[j]), qv = row_sum16(ssq[j]);
+      if (BRED) {
+        const float4 c = lds_cf[ch16 + j];
+        sv = (sv - c.z * qv) * c.w;
+      }
+      o[2 * j] = sv;
+      o[2 * j + 1] = qv;
+    }
+    if (l15 == 0) {
+      float *dst = row + ch16 * 2;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        float sv = row_sum16(ssum[m][j]), qv = row_sum16(ssq[m][j]);
-        if (BRED) {
-          const float4 c = lds_cf[(cw * 2 + m) * 16 + 4 * kp + j];
-          sv = (sv - c.z * qv) * c.w;
-        }
-        o[2 * j] = sv;
-        o[2 * j + 1] = qv;
-      }
-      if (l15 == 0) {
-        float *dst = row + ((cw * 2 + m) * 16 + 4 * kp) * 2;
-        *reinterpret_cast<float4 *>(dst) = make_float4(o[0], o[1], o[2], o[3]);
-        *reinterpret_cast<float4 *>(dst + 4) = make_float4(o[4], o[5], o[6], o[7]);
-      }
+      for (int d = 0; d < 4; ++d)
+        *reinterpret_cast<float4 *>(dst + 4 * d) = make_float4(o[4 * d], o[4 * d + 1], o[4 * d + 2], o[4 * d + 3]);
     }
   }
 }
