@@ -339,6 +339,9 @@ __global__ __launch_bounds__(256, 1) void wgrad_dma_kernel(const WgradArgs a) {
     i_n += img_end;
   };
   auto issue_chunk = [&](unsigned char *dst) {
+#ifdef WGRAD_LAB_NO_LOADS  // laboratory build: only the first three chunks are fetched (what the loads cost the loop)
+    if (i_chunk > c_begin + 3) return;
+#endif
     const unsigned dst_addr = (unsigned)(uintptr_t)(wg_lds_ptr_t)dst + wave * 1024;
 #pragma unroll
     for (int k = 0; k < PER_WAVE; ++k)  // instruction wave + 4 k: dz for k < 4 whatever the wave
