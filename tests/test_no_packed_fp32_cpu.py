@@ -30,3 +30,16 @@ def test_the_scan_sees_instructions():
     assert any("conv3x3_pipe_kernel" in k for k in mfma)
     calls, _, _ = sco.count_per_kernel(r"\bs_swappc_b64\b")
     assert not calls, list(calls)[:5]
+
+
+def test_the_pipelined_convolution_keeps_everything_in_registers():
+    # a spilled register in conv3x3_pipe_kernel is reloaded through vector memory, whose counter the kernel
+    # uses for its direct-to-LDS loads: such a reload waits for every operand in flight (measured: 10-80 %
+    # slower), and an out-of-line lambda would put the accumulators into scratch altogether
+    scratch, _, _ = sco.count_per_kernel(r"\bscratch_(load|store)_")
+    spilled = {k: v for k, v in scratch.items() if "conv3x3_pipe_kernel" in k or "wgrad_dma_kernel" in k}
+    assert not spilled, spilled
+    # and every instance has its 144 MFMAs per stage body (first, middle, last, single stage), not fewer
+    mfma, _, _ = sco.count_per_kernel(r"\bv_mfma_f32_16x16x32_bf16\b")
+    pipe32 = {k: v for k, v in mfma.items() if "conv3x3_pipe_kernel" in k and k.endswith("Li32EEEvNS_4ArgsE")}
+    assert pipe32 and all(v == 4 * 144 for v in pipe32.values()), pipe32
