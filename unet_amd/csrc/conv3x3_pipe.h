@@ -356,7 +356,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pipe_kernel(const Args a) {
   // and then waits at the barrier, while the younger one does most of its MFMAs afterwards.  So the younger half
   // issues its loads at the head of the stage, under the older half's MFMAs, and the older half -- which would
   // otherwise spend the head of every stage issuing loads with both waves of the SIMD off the matrix pipe --
-  // issues its own after LATE_G of the nine MFMA groups, when its partner has MFMAs to fill the gap with.  Not so
+  // issues its own after LATE_G of the nine MFMA groups: after all nine, when it has nothing left to do in this
+  // stage but wait for its partner (measured over LATE_G = 2 .. 9: the later the better, 2 slower than the head,
+  // 9 another 1 - 3 % faster than 4; the loads still land before the partner is through its MFMAs).  Not so
   // in the fused-reduction variant of the layers with resident weights (few channels, full-resolution images: the
   // memory-bound ones, whose last stage also requests the epilogue's operands): measured 2 - 6 % faster with every
   // load out at the head of the stage.
@@ -364,10 +366,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pipe_kernel(const Args a) {
   // barrier instead of with the SIMD waiting for it -- under its partner's MFMAs that epilogue takes twice as
   // long, and the stage it sits in grows by more than the tile's end saves.)
 #ifndef PIPE_LATE_G
-#define PIPE_LATE_G 4  // laboratory builds: 0 = every wave at the head of the stage
+#define PIPE_LATE_G 9  // laboratory builds: 0 = every wave at the head of the stage, 1 .. 8 = the older half between groups
 #endif
   constexpr int LATE_G = (WS && BRED) ? 0 : PIPE_LATE_G;
   const bool late = wave < 4 && LATE_G > 0;
+#if defined(PIPE_LAB_YOUNG_PRIO)  // laboratory builds: the younger half at raised priority for the whole kernel
+  if (wave >= 4) __builtin_amdgcn_s_setprio(PIPE_LAB_YOUNG_PRIO);
+#endif
 
   i32x4 zq[BRED ? QW : 1], oq[EPI == EPI_ACC ? QW : 1];  // what the epilogue reads, requested in a tile's last stage
   f32x4 acc[2][QW];
