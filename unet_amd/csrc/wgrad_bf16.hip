@@ -241,6 +241,12 @@ __device__ __forceinline__ void wg_wait_vmem_then_barrier() {
   asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
 }
 
+#ifdef WGRAD_LAB_STAMPS  // laboratory build: shader-clock stamps of wave 0, printed by two workgroups of every 64th launch
+__device__ int wg_lab_launches;
+#define WG_STAMP(i_) do { if (tid == 0 && (i_) < 36 + 12) st[i_] = __builtin_readcyclecounter(); } while (0)
+#else
+#define WG_STAMP(i_) do { } while (0)
+#endif
 template <int TAPS, int STAGES>
 __global__ __launch_bounds__(256, 1) void wgrad_dma_kernel(const WgradArgs a) {
   constexpr int XR = (TAPS == 9) ? 10 : 8, XC = (TAPS == 9) ? 18 : 16;
@@ -253,6 +259,10 @@ __global__ __launch_bounds__(256, 1) void wgrad_dma_kernel(const WgradArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef WGRAD_LAB_STAMPS
+  unsigned long long *st = reinterpret_cast<unsigned long long *>(lds + 3 * 40 * 1024);
+  WG_STAMP(0);
+#endif
   const int co0 = blockIdx.y * 64, ci0 = blockIdx.z * 64;
   int split = blockIdx.x, phase = 0, dz_oy = a.dz_oy, dz_ox = a.dz_ox;
   if (TAPS == 1 && a.phases > 1) {
@@ -315,6 +325,37 @@ __global__ __launch_bounds__(256, 1) void wgrad_dma_kernel(const WgradArgs a) {
   // MFMAs of a trip so that the compiler spreads it between them; issue_chunk() is then ten load instructions.
   unsigned vo[PER_WAVE];
   i32x4 xrs, zrs;
+  // The same in two steps for the main loop, which spreads the arithmetic over a chunk's rows of MFMAs like the
+  // loads themselves: plan_begin() (scalar: descriptors, origins, the walk), then plan_piece(k) per load into
+  // vo_next; plan_commit() makes it the plan of the next chunk to be issued.
+  unsigned vo_next[PER_WAVE];
+  i32x4 xrs_next, zrs_next;
+  int p_x_org = 0, p_z_org = 0, p_x0_test = 0;
+  auto plan_begin = [&]() {
+    const int y0 = i_cy * 8, x0 = i_cx * 16;
+    p_x0_test = (i_chunk < c_end) ? x0 : -(1 << 24);
+    xrs_next = wg_make_rsrc(a.x + (i64)i_n * a.H * a.W * a.x_ld, x_img_bytes);
+    zrs_next = wg_make_rsrc(a.dz + (i64)i_n * a.Hz * a.Wz * a.dz_ld, z_img_bytes);
+    p_x_org = (y0 * a.W + x0) * a.x_ld * 2;
+    p_z_org = (y0 * a.dz_s * a.Wz + x0 * a.dz_s) * a.dz_ld * 2;
+    ++i_chunk;
+    const bool row_end = ++i_cx == a.chunksX;
+    i_cx = row_end ? 0 : i_cx;
+    i_cy += row_end;
+    const bool img_end = i_cy == a.chunksY;
+    i_cy = img_end ? 0 : i_cy;
+    i_n += img_end;
+  };
+  auto plan_piece = [&](const int k) {
+    const unsigned off = (unsigned)((k < Z_INSTR / 4 ? p_z_org : p_x_org) + rel[k]);
+    vo_next[k] = ((unsigned)(p_x0_test + pxk[k]) < (unsigned)a.W) ? off : OOB;
+  };
+  auto plan_commit = [&]() {
+#pragma unroll
+    for (int k = 0; k < PER_WAVE; ++k) vo[k] = vo_next[k];
+    xrs = xrs_next;
+    zrs = zrs_next;
+  };
   auto plan_chunk = [&]() {
     // Only the pixel column is tested here.  A pixel row above the image makes the offset negative, one below
     // it puts the offset past the image: both are beyond the descriptor (which covers one image of less than
@@ -337,6 +378,15 @@ __global__ __launch_bounds__(256, 1) void wgrad_dma_kernel(const WgradArgs a) {
     const bool img_end = i_cy == a.chunksY;
     i_cy = img_end ? 0 : i_cy;
     i_n += img_end;
+  };
+  // one of the chunk's PER_WAVE load instructions (the main loop spreads them over a chunk's rows of MFMAs: issued
+  // in one block they cost the wave, which is alone on its SIMD, some 600 cycles with nothing on the matrix pipe)
+  auto issue_piece = [&](unsigned char *dst, const int k) {
+#ifdef WGRAD_LAB_NO_LOADS
+    if (i_chunk > c_begin + 3) return;
+#endif
+    const unsigned dst_addr = (unsigned)(uintptr_t)(wg_lds_ptr_t)dst + wave * 1024;
+    wg_lds_load_b128(k < Z_INSTR / 4 ? zrs : xrs, dst_addr + k * 4096, vo[k]);
   };
   auto issue_chunk = [&](unsigned char *dst) {
 #ifdef WGRAD_LAB_NO_LOADS  // laboratory build: only the first three chunks are fetched (what the loads cost the loop)
@@ -373,11 +423,11 @@ __global__ __launch_bounds__(256, 1) void wgrad_dma_kernel(const WgradArgs a) {
     }
   };
   wg_wait_vmem_then_barrier<PER_WAVE>();
-  issue_chunk(lds + 2 * STAGE);
-  plan_chunk();
+  WG_STAMP(1);
   read_row(lds, 0);
   int buf = 0;
   for (int chunk = c_begin; chunk < c_end; ++chunk) {
+    if (chunk - c_begin < 36) WG_STAMP(4 + (chunk - c_begin));
     const unsigned char *cur = lds + buf * STAGE;
     const int nb = buf == 2 ? 0 : buf + 1;
     auto mfma_row = [&](int r) {
@@ -391,9 +441,17 @@ __global__ __launch_bounds__(256, 1) void wgrad_dma_kernel(const WgradArgs a) {
                 __builtin_amdgcn_mfma_f32_32x32x16_bf16(aw[ks & 3], bq[r & 1][kw], acc[kh * 3 + kw], 0, 0, 0);
         }
     };
+    // the loads of the chunk after the next go out one per row, into the buffer the previous chunk was read from
+    // (free since that chunk's barrier)
+    unsigned char *const dst2 = lds + (buf == 0 ? 2 : buf - 1) * STAGE;
+    plan_begin();
 #pragma unroll
     for (int r = 0; r < 9; ++r) {
       read_row(cur, r + 1);
+      issue_piece(dst2, r);
+      if (r == 8) issue_piece(dst2, 9);
+      plan_piece(r);
+      if (r == 8) plan_piece(9);
       mfma_row(r);
     }
     // the order above, pinned for the scheduler: reads of row r + 1, then the MFMAs of row r
@@ -408,15 +466,24 @@ __global__ __launch_bounds__(256, 1) void wgrad_dma_kernel(const WgradArgs a) {
       if (r >= 2 && r < 8) __builtin_amdgcn_sched_group_barrier(0x008, 9, 0);
     }
     __builtin_amdgcn_sched_barrier(0);  // the barrier stays behind the MFMAs of row 8, which cover the reads of row 9
+#ifdef WGRAD_LAB_STAMPS
+    if (chunk == c_begin + 10) WG_STAMP(40);
+#endif
     wg_wait_vmem_then_barrier<PER_WAVE>();
+#ifdef WGRAD_LAB_STAMPS
+    if (chunk == c_begin + 10) WG_STAMP(41);
+#endif
     read_row(lds + nb * STAGE, 0);
-    issue_chunk(lds + buf * STAGE);  // this chunk's own buffer: all of its fragments are in registers
+#ifdef WGRAD_LAB_STAMPS
+    if (chunk == c_begin + 10) WG_STAMP(42);
+#endif
     mfma_row(9);
-    plan_chunk();
+    plan_commit();
     __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
     __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
     buf = nb;
   }
+  WG_STAMP(2);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the loads issued past the end of the slice
   const int slices = (TAPS == 1 && a.phases > 1) ? a.phases : TAPS;
   const auto prs = __builtin_amdgcn_make_buffer_rsrc(a.partial + ((i64)split * slices + phase) * a.CoP * a.CiP, 0,
@@ -434,6 +501,21 @@ __global__ __launch_bounds__(256, 1) void wgrad_dma_kernel(const WgradArgs a) {
     }
     off += (unsigned)a.CoP * row_bytes;
   }
+#ifdef WGRAD_LAB_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  WG_STAMP(3);
+  if (tid == 0 && (blockIdx.x == 0 || blockIdx.x == 3) && blockIdx.y == 0 && blockIdx.z == 0) {
+    const int launch = blockIdx.x == 0 ? atomicAdd(&wg_lab_launches, 1) : wg_lab_launches - 1;
+    if ((launch & 63) == 5) {
+      const int nc = c_end - c_begin;
+      printf("wgrad stamps H %d Ci %d Co %d wg %d: %d chunks; start->first barrier %llu, loop %llu (%llu per chunk), end of loop->loads drained+partial stored %llu; chunk lengths:",
+             a.H, a.CiP, a.CoP, (int)blockIdx.x, nc, st[1] - st[0], st[2] - st[1], (st[2] - st[1]) / (nc > 0 ? nc : 1), st[3] - st[2]);
+      printf(" [chunk 10: rows 0-8 %llu, barrier %llu, reads+loads issued %llu, row 9+plan %llu]", st[40] - st[14], st[41] - st[40], st[42] - st[41], st[15] - st[42]);
+      for (int i = 1; i < nc && i < 12; ++i) printf(" %llu", st[4 + i] - st[4 + i - 1]);
+      printf("\n");
+    }
+  }
+#endif
 }
 
 // grad[(ci*Co + co)*taps_total + tap_base + t] = sum_split partial[split][t][co][ci]
@@ -563,7 +645,11 @@ static int run_wgrad(int taps, int phases, const WgradArgs &base, float *grad, i
   const size_t lds = (size_t)128 * WP + (size_t)(taps == 9 ? 180 : 128) * WP;
   // laboratory switch: 0 = register-staged kernel, 1 = direct-to-LDS, 2 = direct-to-LDS with prefetched fragments
   static const int dma_env = getenv("UNET_LAB_WGRAD_DMA") ? atoi(getenv("UNET_LAB_WGRAD_DMA")) : 2;
+#ifdef WGRAD_LAB_STAMPS
+  const size_t lds_dma = (size_t)3 * 40 * 1024 + 512;
+#else
   const size_t lds_dma = (size_t)3 * 40 * 1024;
+#endif
   static bool attr_set[64] = {};
   int dev = 0;
   UNET_HIP_TRY(hipGetDevice(&dev));
@@ -573,7 +659,7 @@ static int run_wgrad(int taps, int phases, const WgradArgs &base, float *grad, i
     UNET_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&wgrad_mfma_kernel<1>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)((128 + 128) * WP)));
     UNET_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&wgrad_dma_kernel<9, 3>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, 3 * 40 * 1024));
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dma));
     attr_set[dev & 63] = true;
   }
   dim3 grid((unsigned)(splits * phases), (unsigned)(a.CoP / 64), (unsigned)(a.CiP / 64));
