@@ -321,8 +321,8 @@ __global__ __launch_bounds__(256, 1) void wgrad_dma_kernel(const WgradArgs a) {
   // line of code, which lets the compiler spread the address arithmetic between the MFMAs.
   int i_chunk = c_begin, i_n = c_begin / per_img, i_cy = (c_begin - i_n * per_img) / a.chunksX,
       i_cx = c_begin - i_n * per_img - i_cy * a.chunksX;
-  // plan_chunk() works out the addresses of the chunk to be issued next -- plain arithmetic, written after the
-  // MFMAs of a trip so that the compiler spreads it between them; issue_chunk() is then ten load instructions.
+  // plan_chunk() works out the addresses of the chunk to be issued next, issue_chunk() is then ten load
+  // instructions: the prologue's form (the main loop has its own, in pieces, below).
   unsigned vo[PER_WAVE];
   i32x4 xrs, zrs;
   // The same in two steps for the main loop, which spreads the arithmetic over a chunk's rows of MFMAs like the
@@ -404,7 +404,8 @@ __global__ __launch_bounds__(256, 1) void wgrad_dma_kernel(const WgradArgs a) {
   // pipeline does not stop at a chunk's end.  The one barrier of a chunk stands in front of its last halo
   // row: by then a wave has read all of the chunk's fragments and its own pieces of the next chunk have
   // landed (the chunk after that may be in flight); behind the barrier that holds for every wave, so the
-  // next chunk's first row can be read and the loads three chunks ahead can overwrite this chunk.
+  // next chunk's first row can be read, and this chunk's buffer is free for the loads of the chunk three
+  // ahead -- which the next trip issues one per row of MFMAs, with their address arithmetic.
   plan_chunk();
   issue_chunk(lds);
   plan_chunk();
