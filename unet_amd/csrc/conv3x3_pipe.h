@@ -34,6 +34,11 @@
                             // 4 = no operand loads at all after the first stage (matrix cores + LDS reads only)
 #endif
 
+#ifndef PIPE_LAB_NORM_ON_LOAD
+#define PIPE_LAB_NORM_ON_LOAD 0  // laboratory builds only: every pixel fragment goes through relu(a * x + b) after its LDS read
+                                  // (what folding the previous layer's normalisation pass into this kernel would cost;
+                                  // constant a, b: the results are not those of the library)
+#endif
 #ifndef PIPE_LAB_STAMPS
 #define PIPE_LAB_STAMPS 0  // laboratory builds only: clock stamps of the first 16 stages of every wave (Args::lab_stamps)
 #endif
@@ -481,6 +486,21 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pipe_kernel(const Args a) {
   // head_reads: the first tap's fragments (ten pixel rows, two weight blocks), requested back to back: left to
   // itself the scheduler pairs each read with the MFMA that needs it and the head of the stage waits for one
   // LDS round trip per MFMA.
+#if PIPE_LAB_NORM_ON_LOAD
+  auto lab_norm = [&](bf16x8 &f) __attribute__((always_inline)) {
+    const f32x4 lo = __builtin_convertvector(__builtin_shufflevector(f, f, 0, 1, 2, 3), f32x4);
+    const f32x4 hi = __builtin_convertvector(__builtin_shufflevector(f, f, 4, 5, 6, 7), f32x4);
+    const f32x4 a4 = {1.0f, 0.5f, 2.0f, 1.5f}, b4 = {0.01f, -0.02f, 0.03f, 0.0f}, z4 = {0.f, 0.f, 0.f, 0.f};
+    const bf16x4 l = __builtin_convertvector(__builtin_elementwise_max(lo * a4 + b4, z4), bf16x4);
+    const bf16x4 h = __builtin_convertvector(__builtin_elementwise_max(hi * a4 + b4, z4), bf16x4);
+    f = __builtin_shufflevector(l, h, 0, 1, 2, 3, 4, 5, 6, 7);
+  };
+#define PIPE_LAB_NORM(f_) lab_norm(f_)
+#else
+#define PIPE_LAB_NORM(f_) \
+  do {                    \
+  } while (0)
+#endif
   auto head_reads = [&](const unsigned char *ldsX, const unsigned char *ldsW, bf16x8 *brow, bf16x8 *af) __attribute__((always_inline)) {
 #pragma unroll
     for (int r = 0; r < QW + 2; ++r)
@@ -489,6 +509,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pipe_kernel(const Args a) {
     for (int m = 0; m < 2; ++m)
       af[m] = *reinterpret_cast<const bf16x8 *>(ldsW + ((cw * 2 + m) * 16) * 64 + a4_lane);
     __builtin_amdgcn_sched_barrier(0);
+#if PIPE_LAB_NORM_ON_LOAD
+#pragma unroll
+    for (int r = 0; r < QW + 2; ++r) PIPE_LAB_NORM(brow[r]);
+#endif
   };
   // stage_mfma: groups g0 .. g1-1.  A wave's own stream must not wait for LDS: once the older wave of the SIMD
   // is through its stage, the younger one runs alone with nobody to cover its waits.  So the weight fragments of
@@ -517,11 +541,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_pipe_kernel(const Args a) {
 #endif
           acc[m][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cur[m], brow[q + kh],
                                                               (zero_start && g == 0) ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[m][q], 0, 0, 0);
-        if (kh == 2 && kw < 2)
+        if (kh == 2 && kw < 2) {
           brow[q + 2] = *reinterpret_cast<const bf16x8 *>(ldsX + (q + 2) * HC * 64 + b4_off[kw + 1][(q + 2) & 3]);
+          PIPE_LAB_NORM(brow[q + 2]);
+        }
       }
-      if (kh < 2 && kw < 2)
+      if (kh < 2 && kw < 2) {
         brow[kh] = *reinterpret_cast<const bf16x8 *>(ldsX + kh * HC * 64 + b4_off[kw + 1][kh & 3]);
+        PIPE_LAB_NORM(brow[kh]);
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
   };
