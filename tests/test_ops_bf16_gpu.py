@@ -205,14 +205,17 @@ def test_conv3x3_wgrad_long_pixel_slices(G, capi, cfg):
     np.testing.assert_array_equal(G.host(again).reshape(ci, co, 3, 3), got)
 
 
-@pytest.mark.parametrize("case", [(8, 64, 64, 256), (16, 512, 1024, 16), (4, 64, 64, 256), (4, 256, 256, 64)])
+@pytest.mark.parametrize("case", [(8, 64, 64, 256), (16, 512, 1024, 16), (4, 64, 64, 256), (4, 256, 256, 64),
+                                  (6, 128, 128, 72), (8, 64, 192, 40)])
 def test_pipelined_kernel_is_bit_identical_to_the_general_kernel_at_training_sizes(G, capi, case):
     """The two 3x3 kernels on the same operands, forward (with statistics) and data gradient: every output
     bit equal.  At 256 x 256 with batch 8 the data gradient is large enough (67 MB) for the pipelined kernel's
     non-temporal stores, and every workgroup walks several tiles in reversed order; 16 x 16 with 1024 channels
     is the 16-row tile variant at the size the benchmark graph uses it; batch 4 at 256 x 256 takes 16-row tiles
     because 32-row tiles would leave a workgroup two of them (resident weights); batch 4 at 64 x 64 with 256
-    channels because there are fewer 32-row tiles than workgroups (streamed weights)."""
+    channels because there are fewer 32-row tiles than workgroups (streamed weights); 72 x 72 and 40 x 40 have
+    ragged tiles on both sides and tile counts per image (15, 6) that the workgroups' strides do not divide, so
+    the tile walk carries over rows and images unevenly and the masked statistics path runs."""
     n, ci, co, h = case
     w = h
     gen = torch.Generator(device="cpu").manual_seed(h)
