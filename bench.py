@@ -133,6 +133,14 @@ def cpu_baseline_torch(graph, batch=1, steps=1):
     return (time.perf_counter() - t0) / steps, cores
 
 
+def emit_line(rec):
+    """One JSON record as ONE write of the whole line, newline included: the ranks of a launcher share a pipe,
+    and a record written apart from its newline can end up on the same line as another rank's."""
+    sys.stdout.flush()
+    sys.stdout.write(json.dumps(rec) + "\n")
+    sys.stdout.flush()
+
+
 def launch_ranks(args):
     """Started without a launcher but asked for several GPUs: run the same command line under
     torch.distributed.run as a CHILD process (one rank per GPU, rendezvous on 127.0.0.1), relay what it
@@ -201,11 +209,10 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if args.dry_launch:
-        print(json.dumps({"dry_launch_rank": int(os.environ.get("RANK", "0")),
-                          "world_size": int(os.environ.get("WORLD_SIZE", "1")),
-                          "local_rank": int(os.environ.get("LOCAL_RANK", "0")),
-                          "master": f"{os.environ.get('MASTER_ADDR', '-')}:{os.environ.get('MASTER_PORT', '-')}"}),
-              flush=True)
+        emit_line({"dry_launch_rank": int(os.environ.get("RANK", "0")),
+                   "world_size": int(os.environ.get("WORLD_SIZE", "1")),
+                   "local_rank": int(os.environ.get("LOCAL_RANK", "0")),
+                   "master": f"{os.environ.get('MASTER_ADDR', '-')}:{os.environ.get('MASTER_PORT', '-')}"})
         return
     if args.dtype:
         os.environ["UNET_DTYPE"] = args.dtype
@@ -453,7 +460,7 @@ def main():
                                        "sample": f"PyTorch-CPU fp32 fwd+bwd of the same graph, batch 1, {tdt:.1f} s"}
         except Exception as e:  # the torch figure is a side note; never fail the bench on it
             out["cpu_torch_oracle"] = {"error": str(e)[:200]}
-    print(json.dumps(out), flush=True)
+    emit_line(out)
     if world > 1:
         dist.destroy_process_group()
 
