@@ -267,7 +267,12 @@ def test_conv3x3_reads_channel_slices(G, capi, oracle):
     assert_close_bf16(res[..., 32:].transpose(0, 3, 1, 2), y_ref, what="conv into a channel slice")
 
 
-@pytest.mark.parametrize("cfg", [(2, 64, 32, 8, 8), (1, 32, 64, 20, 12), (1, 128, 64, 16, 16)])
+# From the third on: shapes the matrix-product kernel serves (input channels in multiples of 64; the data gradient
+# when its output channels come in multiples of 128): ragged images, one to six reduction chunks (odd counts too),
+# column tiles that span four, two and one output phase, padded output channels.
+@pytest.mark.parametrize("cfg", [(2, 64, 32, 8, 8), (1, 32, 64, 20, 12), (1, 128, 64, 16, 16), (2, 64, 64, 20, 12),
+                                 (1, 128, 64, 20, 28), (3, 192, 128, 16, 32), (2, 256, 128, 24, 16), (1, 128, 40, 16, 16),
+                                 (2, 384, 192, 8, 40)])
 def test_tconv2x2(G, capi, oracle, cfg):
     n, ci, co, h, w = cfg
     cip, cop = pad32(ci), pad32(co)
@@ -288,6 +293,7 @@ def test_tconv2x2(G, capi, oracle, cfg):
     assert_close_bf16(y, oracle.upsample(x, w_and_b, co, 2), what=f"tconv forward {cfg}")
     st = G.host(stats).sum(axis=(0, 1, 2))
     assert_close(st[:co, 0], y.sum(axis=(0, 2, 3)), rtol=1e-4, atol_scale=1e-5, what="tconv stats sum")
+    assert_close(st[:co, 1], (y.astype(np.float64) ** 2).sum(axis=(0, 2, 3)), rtol=1e-4, atol_scale=1e-5, what="tconv stats sum of squares")
     dx_ref, dw_ref = oracle.upsample_backward(x, w_and_b, dy, 2)
     dx = torch.full((n, h, w, cip), float("nan"), dtype=torch.bfloat16, device=G.DEV)
     capi.unet_tconv2x2_dgrad_bf16(G.p(dyt), cop, G.p(bwd), G.p(dx), cip, n, h, w, cip, cop, 0, None)
@@ -502,6 +508,7 @@ def test_bn_act_with_fused_max_pool_forward_and_backward(G, capi, oracle, cfg):
 
 
 @pytest.mark.parametrize("cfg", [("conv", 2, 64, 64, 24, 40), ("conv", 1, 32, 96, 16, 16), ("tconv", 2, 64, 32, 8, 12),
+                                 ("tconv", 2, 128, 64, 20, 28), ("tconv", 1, 256, 128, 16, 16),  # the matrix-product kernel
                                  ("conv", 1, 64, 64, 72, 80),    # the pipelined kernel, weights resident
                                  ("conv", 3, 128, 192, 40, 48),   # the pipelined kernel, six K chunks, two channel blocks
                                  ("conv", 2, 128, 128, 16, 32)])  # its 16-row tiles

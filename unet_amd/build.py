@@ -35,6 +35,9 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 NO_PACKED_FP32 = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize", "-Wall", "-Wno-unused-function",
              "-Wno-unused-variable", "-Wno-unused-but-set-variable"] + NO_PACKED_FP32
+# UNET_LAB_HIPFLAGS="-DTCONV_LAB_STAMPS ...": extra compiler flags of a laboratory build (rebuild with --force, and again
+# without the variable afterwards: the library in the tree is the one the tests and the benchmark load).
+HIP_FLAGS += os.environ.get("UNET_LAB_HIPFLAGS", "").split()
 HOST_PASS_NOISE = "is not a recognized feature for this target (ignoring feature)"
 # Per-file extra flags.  wgrad_bf16: MFMA accumulators stay in ordinary vector registers (no copies
 # to and from the accumulation half of the register file around the loop-carried accumulators).

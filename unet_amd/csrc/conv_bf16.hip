@@ -28,6 +28,7 @@
 //
 #include "bf16_util.h"
 #include "conv3x3_pipe.h"
+#include "tconv_gemm.h"
 
 namespace {
 
@@ -466,8 +467,46 @@ int narrow_block_workgroups() {
   return v;
 }
 
+// The transposed convolution as one matrix product (tconv_gemm.h) for the shapes it serves.  Chosen by SHAPE only,
+// never by batch size: its sums run in another order than the general kernel's, and one image must give the same
+// bits alone and inside a batch.
+bool tconv_gemm_serves(const ConvArgs &c) {
+  const bool fwd = c.out_phases == 4 && c.k_phases == 1 && c.in_s == 1 && c.out_s == 2;
+  const bool dgrad = c.out_phases == 1 && c.k_phases == 4 && c.in_s == 2 && c.out_s == 1;
+  if (tgemm::lab_off() || !(fwd || dgrad) || c.affine || c.in_c != 0 || c.bred_c0 != 0) return false;
+  if (c.in_oy | c.in_ox | c.out_oy | c.out_ox) return false;
+  if (fwd && c.accumulate) return false;
+  const int cols = fwd ? 4 * c.CoP : c.CoP;
+  if (c.Ci % tgemm::KC != 0 || c.CoP % 32 != 0 || cols % tgemm::COLS != 0) return false;
+  if ((((uintptr_t)c.in | (uintptr_t)c.wt | (uintptr_t)c.out | (uintptr_t)c.bz | (uintptr_t)c.bcf) & 15) != 0) return false;
+  if (c.stats && (((uintptr_t)c.stats) & 15) != 0) return false;
+  return (i64)4 * c.CoP * c.Ci * 2 < (1ll << 32);
+}
+int launch_tconv_gemm(const ConvArgs &c, hipStream_t s) {
+  const bool fwd = c.out_phases == 4;
+  tgemm::Args a{};
+  a.in = c.in; a.wt = c.wt; a.bias = c.bias; a.out = c.out; a.stats = c.stats;
+  a.N = c.N; a.Hin = c.Hin; a.Win = c.Win; a.Ho = c.Ho; a.Wo = c.Wo; a.Hout = c.Hout; a.Wout = c.Wout;
+  a.nk1 = c.Ci / tgemm::KC; a.in_s = c.in_s; a.out_s = c.out_s; a.in_ld = c.in_ld; a.out_ld = c.out_ld;
+  a.w_row = c.Ci; a.wt_phase_stride = c.wt_phase_stride; a.wt_bytes = (unsigned)((i64)4 * c.CoP * c.Ci * 2);
+  a.CoP = c.CoP; a.col_tiles = (fwd ? 4 * c.CoP : c.CoP) / tgemm::COLS;
+  a.tilesX = c.tilesX; a.tiles = c.tilesX * ((c.Ho + 15) / 16);
+  a.co_valid = c.co_valid; a.stats_phase_stride = c.stats_phase_stride;
+  a.bz = c.bz; a.bz_ld = c.bz_ld; a.bcf = c.bcf;
+  const i64 grid = (i64)c.N * a.tiles * a.col_tiles;
+  if (grid >= (1ll << 31)) return -1;
+  a.xcd_order = grid % 8 == 0 ? 1 : 0;
+  if (fwd) return c.stats ? tgemm::launch<1, tgemm::EPI_STATS>(a, (int)grid, s) : tgemm::launch<1, tgemm::EPI_PLAIN>(a, (int)grid, s);
+  if (c.bz) return tgemm::launch<4, tgemm::EPI_BRED>(a, (int)grid, s);
+  return c.accumulate ? tgemm::launch<4, tgemm::EPI_ACC>(a, (int)grid, s) : tgemm::launch<4, tgemm::EPI_PLAIN>(a, (int)grid, s);
+}
+
 int launch_conv_any(int taps, const ConvArgs &a, hipStream_t s) {
   if (taps == 9 && pipe::eligible(a.N, a.Ho, a.Wo, a.Ci, a.CoP)) return launch_pipe_from(a, s);
+  if (taps == 1 && tconv_gemm_serves(a)) {
+    const int rc = launch_tconv_gemm(a, s);
+    if (rc >= 0) return rc;
+  }
   const bool wide = a.CoP % 64 == 0, deep = a.Ci % 64 == 0;
   // the 16x16x32 path for every image the pipelined kernel could take at some batch size (16 x 16 pixels and
   // more), and for smaller ones with many tiles.  The choice must not depend on the batch size: the two loops

@@ -42,20 +42,26 @@ constexpr int WP = 192;  // LDS row pitch (bytes) of a 64-channel pixel row: 4 r
 //     answers with zeros (no branches, no selects);
 //   - the per-lane offsets inside a chunk are computed once; a chunk adds one scalar;
 //   - the accumulator tiles stay in ordinary vector registers (see the note on compile flags above).
-template <int TAPS>
+// PH = 4 (TAPS == 1): the four (i, j) phases of the 2x2 transposed convolution in ONE workgroup -- the x tile of a
+// chunk is fetched and read from LDS once and multiplies the dz tiles of the four phases (four accumulator blocks),
+// 32 MFMAs per wave between two barriers instead of 8.  One phase per workgroup (the phase taken from blockIdx.x)
+// ran at the pace of its loads: 32 KB of operands per 8 MFMAs of a wave.
+template <int TAPS, int PH = 1>
 __global__ __launch_bounds__(256, 1) void wgrad_mfma_kernel(const WgradArgs a) {
+  static_assert(PH == 1 || TAPS == 1, "phases are a variant of the single-tap kernel");
   constexpr int XR = (TAPS == 9) ? 10 : 8, XC = (TAPS == 9) ? 18 : 16;
   constexpr int XPIX = XR * XC, ZPIX = 128;
   constexpr int XCH = XPIX * 8, XI = (XCH + 255) / 256;
   constexpr int ZCH = ZPIX * 8, ZI = ZCH / 256;
+  constexpr int NACC = TAPS * PH;
   constexpr unsigned OOB = 0xffffffffu;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  unsigned char *ldsZ = lds, *ldsX = lds + ZPIX * WP;
+  unsigned char *ldsZ = lds, *ldsX = lds + PH * ZPIX * WP;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int co0 = blockIdx.y * 64, ci0 = blockIdx.z * 64;
   int split = blockIdx.x, phase = 0, dz_oy = a.dz_oy, dz_ox = a.dz_ox;
-  if (TAPS == 1 && a.phases > 1) {
+  if (TAPS == 1 && PH == 1 && a.phases > 1) {
     phase = split & 3;
     split >>= 2;
     dz_oy = phase >> 1;
@@ -63,9 +69,9 @@ __global__ __launch_bounds__(256, 1) void wgrad_mfma_kernel(const WgradArgs a) {
   }
   const int wm = wave >> 1, wn = wave & 1;
 
-  f32x16 acc[TAPS];
+  f32x16 acc[NACC];
 #pragma unroll
-  for (int t = 0; t < TAPS; ++t)
+  for (int t = 0; t < NACC; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
@@ -101,7 +107,11 @@ __global__ __launch_bounds__(256, 1) void wgrad_mfma_kernel(const WgradArgs a) {
   const unsigned x_img_bytes = (unsigned)a.H * a.W * a.x_ld * 2u, z_img_bytes = (unsigned)a.Hz * a.Wz * a.dz_ld * 2u;
   const int st_off = (tid >> 3) * WP + (tid & 7) * 16;  // piece i sits 32 pixel rows further
 
-  i32x4 xr[XI], zr[ZI];
+  // PH > 1: phase p = 2 i + j reads the dz pixel (i, j) further (a scalar offset of the load)
+  unsigned ph_off[PH];
+#pragma unroll
+  for (int p = 0; p < PH; ++p) ph_off[p] = (unsigned)((((p >> 1) * a.Wz + (p & 1)) * a.dz_ld) * 2);
+  i32x4 xr[XI], zr[PH][ZI];
   auto load_chunk = [&](int chunk) {
     const int n = chunk / per_img, r = chunk - n * per_img;
     const int cy = r / a.chunksX;
@@ -120,7 +130,9 @@ __global__ __launch_bounds__(256, 1) void wgrad_mfma_kernel(const WgradArgs a) {
 #pragma unroll
     for (int i = 0; i < ZI; ++i) {
       const bool ok = (unsigned)(y0 + z_py[i]) < (unsigned)a.H && (unsigned)(x0 + z_px[i]) < (unsigned)a.W;
-      zr[i] = __builtin_amdgcn_raw_buffer_load_b128(zrs, ok ? z_org + z_rel[i] : OOB, 0, 0);
+#pragma unroll
+      for (int p = 0; p < PH; ++p)
+        zr[p][i] = __builtin_amdgcn_raw_buffer_load_b128(zrs, ok ? z_org + z_rel[i] : OOB, PH > 1 ? ph_off[p] : 0, 0);
     }
   };
   auto store_chunk = [&]() {
@@ -128,7 +140,9 @@ __global__ __launch_bounds__(256, 1) void wgrad_mfma_kernel(const WgradArgs a) {
     for (int i = 0; i < XI; ++i)
       if (XCH % 256 == 0 || tid + 256 * i < XCH) *reinterpret_cast<i32x4 *>(ldsX + st_off + i * 32 * WP) = xr[i];
 #pragma unroll
-    for (int i = 0; i < ZI; ++i) *reinterpret_cast<i32x4 *>(ldsZ + st_off + i * 32 * WP) = zr[i];
+    for (int p = 0; p < PH; ++p)
+#pragma unroll
+      for (int i = 0; i < ZI; ++i) *reinterpret_cast<i32x4 *>(ldsZ + p * ZPIX * WP + st_off + i * 32 * WP) = zr[p][i];
   };
 
   load_chunk(c_begin);
@@ -168,13 +182,13 @@ __global__ __launch_bounds__(256, 1) void wgrad_mfma_kernel(const WgradArgs a) {
     } else {
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks) {
-        const unsigned char *zp = ldsZ + ks * 16 * WP + z_lane;
-        const bf16x8 af = tr_read_pair(zp, zp + 4 * WP);
+        const unsigned char *xp = ldsX + ks * XC * WP + x_lane;
+        const bf16x8 bfr = tr_read_pair(xp, xp + 4 * WP);
 #pragma unroll
-        for (int t = 0; t < TAPS; ++t) {
-          const unsigned char *xp = ldsX + ks * XC * WP + x_lane;
-          const bf16x8 bfr = tr_read_pair(xp, xp + 4 * WP);
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, acc[t], 0, 0, 0);
+        for (int p = 0; p < PH; ++p) {
+          const unsigned char *zp = ldsZ + p * ZPIX * WP + ks * 16 * WP + z_lane;
+          const bf16x8 af = tr_read_pair(zp, zp + 4 * WP);
+          acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, acc[p], 0, 0, 0);
         }
       }
     }
@@ -187,11 +201,11 @@ __global__ __launch_bounds__(256, 1) void wgrad_mfma_kernel(const WgradArgs a) {
   // partial[split][tap][co][ci] through one descriptor per split slice and 32-bit offsets
   const int slices = (TAPS == 1 && a.phases > 1) ? a.phases : TAPS;  // tap slices per split in the partial buffer
   const auto prs = __builtin_amdgcn_make_buffer_rsrc(a.partial + ((i64)split * slices + phase) * a.CoP * a.CiP, 0,
-                                                     (unsigned)TAPS * a.CoP * a.CiP * 4u, 0x00020000);
+                                                     (unsigned)NACC * a.CoP * a.CiP * 4u, 0x00020000);
   const unsigned row_bytes = (unsigned)a.CiP * 4u;
   unsigned off = ((unsigned)(co0 + wm * 32 + 4 * (lane >> 5)) * a.CiP + ci0 + wn * 32 + (lane & 31)) * 4u;
 #pragma unroll
-  for (int t = 0; t < TAPS; ++t) {
+  for (int t = 0; t < NACC; ++t) {
     unsigned o = off;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {  // register r holds row (r&3) + 8*(r>>2) (+ 4*(lane>>5))
@@ -634,7 +648,10 @@ static int run_wgrad(int taps, int phases, const WgradArgs &base, float *grad, i
   // and two workgroups per CU hide each other's staging
   const bool long_slices = (i64)a.total_chunks * tiles >= (i64)48 * 512;
   const int target_blocks = (taps == 9 && !long_slices) ? 256 : 512;
-  int splits = (target_blocks / phases + tiles - 1) / tiles;
+  // (transposed convolution: all four phases in one workgroup, one workgroup per CU -- see wgrad_mfma_kernel's PH)
+  static const bool lab_phase_wgs = getenv("UNET_LAB_TCONV_WGRAD_PHASE_WGS") != nullptr;  // laboratory switch: one phase per workgroup
+  const bool joint = phases == 4 && !lab_phase_wgs;
+  int splits = joint ? (256 + tiles - 1) / tiles : (target_blocks / phases + tiles - 1) / tiles;
   if (splits > a.total_chunks) splits = a.total_chunks;
   if (splits < 1) splits = 1;
   a.chunks_per_split = (a.total_chunks + splits - 1) / splits;
@@ -659,15 +676,17 @@ static int run_wgrad(int taps, int phases, const WgradArgs &base, float *grad, i
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)((128 + 180) * WP)));
     UNET_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&wgrad_mfma_kernel<1>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)((128 + 128) * WP)));
+    UNET_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&wgrad_mfma_kernel<1, 4>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)((4 * 128 + 128) * WP)));
     UNET_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(&wgrad_dma_kernel<9, 3>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dma));
     attr_set[dev & 63] = true;
   }
-  dim3 grid((unsigned)(splits * phases), (unsigned)(a.CoP / 64), (unsigned)(a.CiP / 64));
+  dim3 grid((unsigned)(joint ? splits : splits * phases), (unsigned)(a.CoP / 64), (unsigned)(a.CiP / 64));
   const double partial_bytes = 4.0 * splits * slices * a.CoP * a.CiP;
   {
     ProfScope prof(taps == 9 ? PROF_CONV_WGRAD_BF16 : PROF_TCONV_WGRAD_BF16, flops,
-                   2.0 * a.N * a.H * a.W * ((double)a.x_c * phases + (double)a.z_c * phases) + partial_bytes, s);
+                   2.0 * a.N * a.H * a.W * ((double)a.x_c * (joint ? 1 : phases) + (double)a.z_c * phases) + partial_bytes, s);
     // the direct-to-LDS kernel relies on one image staying below 2^30 bytes (see plan_chunk)
     const bool small_images = (i64)a.H * a.W * a.x_ld * 2 < (1ll << 30) && (i64)a.Hz * a.Wz * a.dz_ld * 2 < (1ll << 30);
     const int dma = small_images ? dma_env : 0;
@@ -675,6 +694,8 @@ static int run_wgrad(int taps, int phases, const WgradArgs &base, float *grad, i
       hipLaunchKernelGGL((wgrad_dma_kernel<9, 3>), grid, dim3(256), lds_dma, s, a);
     else if (taps == 9)
       hipLaunchKernelGGL(wgrad_mfma_kernel<9>, grid, dim3(256), lds, s, a);
+    else if (joint)
+      hipLaunchKernelGGL((wgrad_mfma_kernel<1, 4>), grid, dim3(256), (size_t)(4 * 128 + 128) * WP, s, a);
     else
       hipLaunchKernelGGL(wgrad_mfma_kernel<1>, grid, dim3(256), lds, s, a);
   }
