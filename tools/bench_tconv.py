@@ -6,6 +6,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 from unet_amd import capi
+if os.environ.get("UNET_LAB_LIB"):  # a laboratory build of the library (tools/bin/libunet_hip_*.so) instead of the one in the tree
+    capi.LIB_PATH = os.path.join(ROOT, os.environ["UNET_LAB_LIB"])
 dev = torch.device("cuda", 0); capi.unet_set_device(0)
 N = 16
 

@@ -68,6 +68,11 @@ struct Args {
   const float4 *bcf;
 };
 
+#ifndef TCONV_LAB_ABLATE
+#define TCONV_LAB_ABLATE 0  // laboratory builds only (wrong results, timing only; bits add): 1 = no pixel loads and LDS
+                             // writes after the first two chunks, 2 = no weight loads after them, 4 = six pixel
+                             // fragments per chunk read from LDS instead of 32
+#endif
 #ifdef TCONV_LAB_STAMPS  // laboratory build: shader-clock stamps of wave 0 of two workgroups, printed by every 32nd launch
 __device__ int tg_lab_launches;
 #define TG_STAMP(i_) do { if (tid == 0 && (i_) < 40) st[i_] = __builtin_readcyclecounter(); } while (0)
@@ -137,8 +142,14 @@ __global__ __launch_bounds__(256, 2) void tconv_gemm_kernel(const Args a) {
       xs += (unsigned)(((ld_kph >> 1) * a.Win + (ld_kph & 1)) * a.in_ld) * 2u;
       ws += (unsigned)(ld_kph * a.wt_phase_stride) * 2u;
     }
+#if TCONV_LAB_ABLATE & 1
+    if (ld_kc < 2)
+#endif
 #pragma unroll
     for (int i = 0; i < 8; ++i) xdst[i] = __builtin_amdgcn_raw_buffer_load_b128(xrs, live ? x_voff[i] : OOB, xs, 0);
+#if TCONV_LAB_ABLATE & 2
+    if (ld_kc < 2)
+#endif
 #pragma unroll
     for (int cf = 0; cf < 2; ++cf)
 #pragma unroll
@@ -148,6 +159,9 @@ __global__ __launch_bounds__(256, 2) void tconv_gemm_kernel(const Args a) {
     if (++ld_kin == a.nk1) ld_kin = 0, ++ld_kph;
   };
   auto store_x = [&](int buf, const i32x4 *xsrc) __attribute__((always_inline)) {
+#if TCONV_LAB_ABLATE & 1
+    if (ld_kc > 2) return;
+#endif
 #pragma unroll
     for (int i = 0; i < 8; ++i) *reinterpret_cast<i32x4 *>(lds + buf * STAGE + st_off + i * 2048) = xsrc[i];
   };
@@ -173,7 +187,7 @@ __global__ __launch_bounds__(256, 2) void tconv_gemm_kernel(const Args a) {
 #pragma unroll
       for (int cf = 0; cf < 2; ++cf)
         acc[cf][pf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w[cf * 2 + h]), b[i % RING], acc[cf][pf], 0, 0, 0);
-      if (i + RING < 32)
+      if (i + RING < 32 && !(TCONV_LAB_ABLATE & 4))
         b[i % RING] = *reinterpret_cast<const bf16x8 *>(st + ((i + RING) >> 4) * SUB + ((i + RING) & 15) * 1024);
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -181,9 +195,12 @@ __global__ __launch_bounds__(256, 2) void tconv_gemm_kernel(const Args a) {
 
   // ---- main loop: chunk kc is computed from stage buffer kc & 1 with the weight fragments wq[kc & 1]; behind its
   // MFMAs the pixels of chunk kc + 1 (requested a chunk ago) are written to the other buffer and chunk kc + 2 is
-  // requested into the registers that frees.  (A second set of staging registers, requests two chunks ahead and one
-  // workgroup per CU measured the same on the deep layers and slower on the others: the chunks do not wait for
-  // latency but for the rate at which a CU fetches -- see the clock stamps of the TCONV_LAB_STAMPS build.) ----
+  // requested into the registers that frees.  Measured and not kept: a second set of staging registers with requests
+  // two chunks ahead and one workgroup per CU (the same time on the layers with many channels, slower on the
+  // others), and eight waves per workgroup on the same tile for the launches of one workgroup per CU (8 % slower).
+  // Those launches do not wait for latency: without its pixel loads the 1024 -> 512 layer at 16 x 16 takes 19.9 us
+  // instead of 26.7, with nothing but its MFMAs 17.6 -- what is left is the traffic between L2 and the CUs, 16 column
+  // tiles fetching every pixel tile (TCONV_LAB_ABLATE, TCONV_LAB_STAMPS builds). ----
   request(xr, wq[0]);
   store_x(0, xr);
   request(xr, wq[1]);
