@@ -480,7 +480,12 @@ bool tconv_gemm_serves(const ConvArgs &c) {
   if (c.Ci % tgemm::KC != 0 || c.CoP % 32 != 0 || cols % tgemm::COLS != 0) return false;
   if ((((uintptr_t)c.in | (uintptr_t)c.wt | (uintptr_t)c.out | (uintptr_t)c.bz | (uintptr_t)c.bcf) & 15) != 0) return false;
   if (c.stats && (((uintptr_t)c.stats) & 15) != 0) return false;
-  return (i64)4 * c.CoP * c.Ci * 2 < (1ll << 32);
+  // lanes outside the image address 2^31 bytes into their descriptor: every image must end below that
+  const i64 lim = 1ll << 31;
+  if ((i64)c.Hin * c.Win * c.in_ld * 2 >= lim || (i64)c.Hout * c.Wout * c.out_ld * 2 >= lim ||
+      (c.bz && (i64)c.Hout * c.Wout * c.bz_ld * 2 >= lim))
+    return false;
+  return (i64)4 * c.CoP * c.Ci * 2 < lim;
 }
 int launch_tconv_gemm(const ConvArgs &c, hipStream_t s) {
   const bool fwd = c.out_phases == 4;

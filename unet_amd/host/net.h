@@ -1533,8 +1533,11 @@ class Net {
           // When this is the only gradient the parent's output receives and the parent is a
           // BN + ReLU layer, the data-gradient kernel also does the pixel reduction of the parent's
           // batch-norm backward.
+          // UNET_LAB_BRED_MIN_CHANNELS = c: laboratory switch, no fusion into 3x3 data gradients whose output gradient has
+          // fewer than c channels (the parent's reduction then runs as a pass of its own)
+          static const int lab_min_c = getenv("UNET_LAB_BRED_MIN_CHANNELS") ? atoi(getenv("UNET_LAB_BRED_MIN_CHANNELS")) : 0;
           const bool fuse = p.has_params() && !p.narrow && p.num_children == 1 && p.concat_child < 0 && !p.g_written &&
-                            act_code(p) == 0;
+                            act_code(p) == 0 && !(n.type == CONV_LAYER && n.cop < lab_min_c);
           if (fuse) {
             if (n.type == CONV_LAYER)
               UNET_CALL(unet_conv3x3_dgrad_bnred_bf16(dz, n.cop, n.w_bwd.u16(), p.gb.u16(), p.cop, p.zb.u16(), p.cop,
