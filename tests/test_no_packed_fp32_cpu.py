@@ -39,6 +39,10 @@ def test_the_pipelined_convolution_keeps_everything_in_registers():
     scratch, _, _ = sco.count_per_kernel(r"\bscratch_(load|store)_")
     spilled = {k: v for k, v in scratch.items() if "conv3x3_pipe_kernel" in k or "wgrad_dma_kernel" in k}
     assert not spilled, spilled
+    # the transposed-convolution matrix product keeps 128 accumulators, two sets of weight fragments and a chunk of
+    # staged pixels in 256 registers: a deeper fragment ring has put its fused-reduction instance into spills before
+    spilled = {k: v for k, v in scratch.items() if "tconv_gemm_kernel" in k}
+    assert not spilled, spilled
     # and every instance has its 144 MFMAs per stage body (first, middle, last, single stage), not fewer
     mfma, _, _ = sco.count_per_kernel(r"\bv_mfma_f32_16x16x32_bf16\b")
     pipe32 = {k: v for k, v in mfma.items() if "conv3x3_pipe_kernel" in k and k.endswith("Li32EEEvNS_4ArgsE")}
