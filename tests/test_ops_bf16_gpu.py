@@ -305,6 +305,25 @@ def test_tconv2x2(G, capi, oracle, cfg):
     assert np.abs(got - ref).max() <= 1e-3 * np.abs(ref).max(), (np.abs(got - ref).max(), np.abs(ref).max())
 
 
+@pytest.mark.parametrize("cfg", [(2, 64, 32, 8, 8), (1, 128, 64, 20, 28), (2, 256, 128, 24, 16)])
+def test_tconv2x2_dgrad_accumulates_into_a_gradient(G, capi, cfg):
+    """accumulate = 1 (a second consumer of the same tensor): the stored sum is bf16(bf16(dx) + old), whichever of
+    the two data-gradient kernels the shape selects (general for the first shape, matrix product for the others)."""
+    n, ci, co, h, w = cfg
+    rng = np.random.default_rng(17)
+    wt = bf16_round(rng.standard_normal(ci * co * 4) * (1.0 / np.sqrt(co)))
+    _, bwd = pack(G, capi, wt, ci, co, 2)
+    dyt = torch.from_numpy(rng.standard_normal((n, 2 * h, 2 * w, co)).astype(np.float32)).to(G.DEV).bfloat16()
+    old = torch.from_numpy(rng.standard_normal((n, h, w, ci)).astype(np.float32)).to(G.DEV).bfloat16()
+    dx = torch.full((n, h, w, ci), float("nan"), dtype=torch.bfloat16, device=G.DEV)
+    capi.unet_tconv2x2_dgrad_bf16(G.p(dyt), co, G.p(bwd), G.p(dx), ci, n, h, w, ci, co, 0, None)
+    acc = old.clone()
+    capi.unet_tconv2x2_dgrad_bf16(G.p(dyt), co, G.p(bwd), G.p(acc), ci, n, h, w, ci, co, 1, None)
+    torch.cuda.synchronize()
+    assert torch.isfinite(dx.float()).all() and dx.float().abs().max() > 0
+    assert torch.equal(acc, (dx.float() + old.float()).bfloat16())
+
+
 # ------------------------------------------------ fused BN / activation ----
 def nhwc_tensor(G, x, ld=None):
     """x [N,C,H,W] float (bf16-representable) -> NHWC bf16 device tensor with pixel stride ld."""
